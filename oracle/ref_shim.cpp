@@ -1,0 +1,208 @@
+/* TEST INFRASTRUCTURE ONLY -- never linked into or called from the product path.
+ *
+ * Thin extern "C" shim over the *unmodified* reference translation units
+ * (compiled where they lie under /root/reference by oracle/Makefile into
+ * oracle/_ref/).  It exposes the reference's own C primitives
+ * (source/common/pixel.cpp, ipfilter.cpp), MV-cost table
+ * (source/encoder/bitcost.cpp) and MotionEstimate::motionEstimate
+ * (source/encoder/motion.cpp:277-866) through plain-C entry points so that
+ * the CPU restatement in oracle/me_oracle.c can be validated against the real
+ * reference and golden vectors can be generated from it.
+ *
+ * Built twice: -DHIGH_BIT_DEPTH=0 (pixel = uint8_t) and =1 (pixel = uint16_t).
+ */
+#include "primitives.h"
+#include "common.h"
+#include "motion.h"
+#include "bitcost.h"
+#include "mv.h"
+#include "TLibCommon/TComRom.h"
+
+#include <string.h>
+#include <stdint.h>
+
+using namespace x265;
+
+namespace {
+/* BitCost keeps the per-QP table pointer protected (bitcost.h:57-65); a
+ * subclass can read it after setQP(). */
+struct CostPeek : public BitCost
+{
+    const uint16_t *table() const { return m_cost; }
+};
+
+struct RefME
+{
+    MotionEstimate me;
+    ReferencePlanes planes;
+};
+
+bool g_init = false;
+}
+
+extern "C" {
+
+int ref_pixel_bytes(void) { return (int)sizeof(pixel); }
+
+int ref_init(void)
+{
+    if (!g_init)
+    {
+        x265_param_t param;
+        memset(&param, 0, sizeof(param));
+        param.logLevel = X265_LOG_NONE;
+        /* cpuid = 1: C primitives only (primitives.cpp:129-139 loops from 2) */
+        x265_setup_primitives(&param, 1);
+        g_init = true;
+    }
+    return 0;
+}
+
+void ref_set_bit_depth(int depth)
+{
+#if HIGH_BIT_DEPTH
+    x265::g_bitDepth = depth;
+#else
+    (void)depth;
+#endif
+}
+
+/* kind: 0 sad, 1 satd, 2 sa8d_inter (index = Partitions enum), 3 sa8d (index = SquareBlocks) */
+int ref_cmp(int kind, int idx, pixel *fenc, intptr_t fencstride, pixel *fref, intptr_t frefstride)
+{
+    ref_init();
+    switch (kind)
+    {
+    case 0: return primitives.sad[idx](fenc, fencstride, fref, frefstride);
+    case 1: return primitives.satd[idx](fenc, fencstride, fref, frefstride);
+    case 2: return primitives.sa8d_inter[idx](fenc, fencstride, fref, frefstride);
+    case 3: return primitives.sa8d[idx](fenc, fencstride, fref, frefstride);
+    }
+    return -1;
+}
+
+void ref_sad_x3(int part, pixel *fenc, pixel *r0, pixel *r1, pixel *r2, intptr_t stride, int *res)
+{
+    ref_init();
+    primitives.sad_x3[part](fenc, r0, r1, r2, stride, res);
+}
+
+void ref_sad_x4(int part, pixel *fenc, pixel *r0, pixel *r1, pixel *r2, pixel *r3, intptr_t stride, int *res)
+{
+    ref_init();
+    primitives.sad_x4[part](fenc, r0, r1, r2, r3, stride, res);
+}
+
+int ref_partition_from_sizes(int w, int h) { return PartitionFromSizes(w, h); }
+
+/* kind: 0 = ipfilter_pp[H_8], 1 = ipfilter_pp[V_8] (pixel -> pixel) */
+void ref_ipfilter_pp(int kind, pixel *src, intptr_t srcStride, pixel *dst, intptr_t dstStride, int w, int h, int frac)
+{
+    ref_init();
+    primitives.ipfilter_pp[kind ? FILTER_V_P_P_8 : FILTER_H_P_P_8](src, srcStride, dst, dstStride, w, h, g_lumaFilter[frac]);
+}
+
+void ref_ipfilter_ps_h(pixel *src, intptr_t srcStride, short *dst, intptr_t dstStride, int w, int h, int frac)
+{
+    ref_init();
+    primitives.ipfilter_ps[FILTER_H_P_S_8](src, srcStride, dst, dstStride, w, h, g_lumaFilter[frac]);
+}
+
+void ref_ipfilter_sp_v(short *src, intptr_t srcStride, pixel *dst, intptr_t dstStride, int w, int h, int frac)
+{
+    ref_init();
+    primitives.ipfilter_sp[FILTER_V_S_P_8](src, srcStride, dst, dstStride, w, h, g_lumaFilter[frac]);
+}
+
+void ref_lowres_core(pixel *src0, pixel *dst0, pixel *dsth, pixel *dstv, pixel *dstc,
+                     intptr_t src_stride, intptr_t dst_stride, int width, int height)
+{
+    ref_init();
+    primitives.frame_init_lowres_core(src0, dst0, dsth, dstv, dstc, src_stride, dst_stride, width, height);
+}
+
+/* out[i + 32768] = table[i] for i in [-32767, 32767]; out[0] (i = -32768) is
+ * never written by the reference (bitcost.cpp:52-56) and is reported as 0. */
+void ref_mvcost_table(int qp, uint16_t *out)
+{
+    CostPeek b;
+    b.setQP(qp);
+    const uint16_t *t = b.table();
+    out[0] = 0;
+    for (int i = -32767; i <= 32767; i++)
+        out[i + 32768] = t[i];
+}
+
+/* mvcost / bitcost of q-pel mv relative to q-pel mvp at qp (bitcost.h:43-53) */
+void ref_mvcost(int qp, int mvpx, int mvpy, int mvx, int mvy, int *lambda_cost, int *bits)
+{
+    CostPeek b;
+    b.setQP(qp);
+    b.setMVP(MV((int16_t)mvpx, (int16_t)mvpy));
+    *lambda_cost = b.mvcost(MV((int16_t)mvx, (int16_t)mvy));
+    *bits = b.bitcost(MV((int16_t)mvx, (int16_t)mvy));
+}
+
+void *ref_me_new(void)
+{
+    ref_init();
+    return new RefME;
+}
+
+void ref_me_free(void *h) { delete (RefME*)h; }
+
+/* One full reference call sequence:
+ *   setQP; setSearchMethod; setSubpelRefine; setSourcePlane; setSourcePU; motionEstimate
+ * enc / ref point at pixel (0,0) of border-extended planes.
+ * lowres: if non-NULL, 4 plane pointers (F,H,V,C) and isLowres = true.
+ * mv arguments are {x, y} int16 pairs.  Returns bcost; out_mv = q-pel MV. */
+int ref_me_search(void *h,
+                  pixel *enc, intptr_t encStride,
+                  pixel *ref, intptr_t refStride, pixel **lowres,
+                  int puOffset, int w, int hgt,
+                  const int16_t *mvmin, const int16_t *mvmax, const int16_t *qmvp,
+                  int numc, const int16_t *mvc, int merange,
+                  int method, int subme, int qp, int16_t *out_mv)
+{
+    RefME *r = (RefME*)h;
+    r->me.setQP(qp);
+    r->me.setSearchMethod(method);
+    r->me.setSubpelRefine(subme);
+    r->me.setSourcePlane(enc, encStride);
+    r->me.setSourcePU(puOffset, w, hgt);
+    r->planes.fpelPlane = ref;
+    r->planes.lumaStride = (int)refStride;
+    r->planes.isLowres = lowres != NULL;
+    if (lowres)
+        for (int i = 0; i < 4; i++)
+            r->planes.lowresPlane[i] = lowres[i];
+    else
+        r->planes.lowresPlane[0] = ref;
+    MV cand[16];
+    for (int i = 0; i < numc && i < 16; i++)
+        cand[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out;
+    int cost = r->me.motionEstimate(&r->planes,
+                                    MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]),
+                                    MV(qmvp[0], qmvp[1]), numc, cand, merange, out);
+    out_mv[0] = out.x;
+    out_mv[1] = out.y;
+    return cost;
+}
+
+/* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */
+int ref_me_buf(void *h, int kind, pixel *enc, intptr_t encStride, int puOffset, int w, int hgt,
+               pixel *fref, intptr_t stride)
+{
+    RefME *r = (RefME*)h;
+    r->me.setSourcePlane(enc, encStride);
+    r->me.setSourcePU(puOffset, w, hgt);
+    switch (kind)
+    {
+    case 0: return r->me.bufSAD(fref, stride);
+    case 1: return r->me.bufSATD(fref, stride);
+    case 2: return r->me.bufSA8D(fref, stride);
+    }
+    return -1;
+}
+} // extern "C"

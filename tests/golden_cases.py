@@ -1,0 +1,159 @@
+"""Deterministic inputs of the golden-vector suites.
+
+The expected outputs under tests/golden/ were produced by running the *compiled reference*
+(oracle/_ref) on exactly these inputs (oracle/gen_golden.py).  The same inputs are replayed
+against the CPU restatement (not-gpu tests) and against the HIP path (gpu tests).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from x265_amd import jobs as J  # noqa: E402
+from x265_amd import synth  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+PRIM_ITERS = 25
+PRIM_INCR = 32
+PRIM_STRIDE = 64
+PRIM_BUFSIZE = PRIM_STRIDE * (64 + 16) + PRIM_INCR * 100   # buffer recipe of source/test/pixelharness.cpp:49-80
+
+
+def prim_buffers(bits: int):
+    """Two random pixel buffers (PixelHarness recipe, values 0..255 or 0..1023) + adversarial pairs."""
+    rng = np.random.default_rng(1000 + bits)
+    dt = np.uint8 if bits == 8 else np.uint16
+    mx = 255 if bits == 8 else 1023
+    a = rng.integers(0, mx + 1, PRIM_BUFSIZE).astype(dt)
+    b = rng.integers(0, mx + 1, PRIM_BUFSIZE).astype(dt)
+    z = np.zeros(PRIM_BUFSIZE, dt)
+    m = np.full(PRIM_BUFSIZE, mx, dt)
+    cb = np.where((np.arange(PRIM_BUFSIZE) % 2) == 0, mx, 0).astype(dt)
+    adversarial = [(z, m), (m, z), (cb, z), (cb, m), (cb, np.roll(cb, 1))]
+    return a, b, adversarial
+
+
+IP_SIZES = ((8, 8), (16, 16), (64, 64), (65, 64), (64, 65), (12, 16), (4, 4))
+
+
+def ip_source(bits: int):
+    rng = np.random.default_rng(2000 + bits)
+    dt = np.uint8 if bits == 8 else np.uint16
+    mx = 255 if bits == 8 else 1023
+    h, w = 96, 112
+    src = rng.integers(0, mx + 1, (h, w)).astype(dt)
+    # a band of extreme values to exercise the clips and the short casts
+    src[40:48, :] = mx
+    src[48:56, ::2] = 0
+    ssrc = rng.integers(-12000, 12000, (h, w)).astype(np.int16)
+    return src, ssrc
+
+
+MV_QPS = (0, 12, 22, 27, 32, 37, 51)
+
+SEARCH_W, SEARCH_H = 416, 240
+SEARCH_SHAPES = ((64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 64), (16, 64), (64, 16), (8, 4),
+                 (4, 8), (12, 16), (24, 32), (48, 64), (4, 4), (32, 8), (16, 12))
+SEARCH_SUBME = (0, 1, 2, 5, 7)
+
+
+def search_frames(bits: int, kind: str):
+    return synth.make_sequence(SEARCH_W, SEARCH_H, 3, seed=77 + bits, bit_depth=8 if bits == 8 else 10, kind=kind)
+
+
+def search_jobs(bits: int) -> np.ndarray:
+    """Job grid: 5 methods x 5 subme levels x 16 PU shapes x 3 predictor modes x ranges x QPs.
+    ref_idx alternates between two reference frames."""
+    rng = np.random.default_rng(3000 + bits)
+    W, H = SEARCH_W, SEARCH_H
+    out = []
+    for method in range(5):
+        for subme in SEARCH_SUBME:
+            for (w, h) in SEARCH_SHAPES:
+                if method == J.UMH and w == 4 and h == 4:
+                    continue  # the reference asserts on UMH with 4x4 (motion.cpp:447)
+                for mode in range(3):
+                    merange = 16 if method == J.FULL else int(rng.choice([16, 64, 57]))
+                    n = 1 if method == J.FULL else 3
+                    px = rng.integers(0, (W - w) // 4 + 1, n) * 4
+                    py = rng.integers(0, (H - h) // 4 + 1, n) * 4
+                    if rng.random() < 0.25:   # picture corners / edges: clipped ranges
+                        px[0] = 0 if rng.random() < 0.5 else W - w
+                        py[0] = 0 if rng.random() < 0.5 else H - h
+                    if mode == 0:
+                        qmvp, mvc = (0, 0), None
+                    elif mode == 1:
+                        qmvp, mvc = (int(rng.integers(-60, 60)), int(rng.integers(-60, 60))), None
+                    else:
+                        qmvp = (int(rng.integers(-200, 200)), int(rng.integers(-200, 200)))
+                        k = int(rng.integers(1, 5))
+                        mvc = rng.integers(-150, 150, (k, 2))
+                        if rng.random() < 0.3:
+                            mvc[0] = 0
+                    out.append(J.make_jobs(W, H, px, py, w, h, method=method, subme=subme, merange=merange,
+                                           qp=int(rng.choice([22, 32, 12, 45])), qmvp=qmvp, mvc=mvc,
+                                           ref_idx=int(rng.integers(0, 2))))
+    return np.concatenate(out)
+
+
+FIELD_W, FIELD_H = 256, 128
+
+
+def field_frames():
+    return synth.make_sequence(FIELD_W, FIELD_H, 2, seed=4242, bit_depth=8, kind="motion")
+
+
+def field_jobs() -> np.ndarray:
+    """Whole-frame FULL-search field (all 64/32/16/8 square PUs, merange 24, subme 0)."""
+    return J.frame_jobs(FIELD_W, FIELD_H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Suite runners.  `impl` is any object with the primitive-level interface of
+# tests/oracle_ffi.py (Reference / Oracle) or the product adapter of the gpu tests.
+
+def run_prim_suite(impl, bits: int) -> dict:
+    a, b, adversarial = prim_buffers(bits)
+    res = {}
+    cmpv = np.zeros((3, 64, PRIM_ITERS), dtype=np.int32)
+    for kind in range(3):
+        for part in range(64):
+            for it in range(PRIM_ITERS):
+                cmpv[kind, part, it] = impl.cmp(kind, part, a, 0, PRIM_STRIDE, b, it * PRIM_INCR, PRIM_STRIDE)
+    res["cmp"] = cmpv
+    res["sa8d_sq"] = np.array([impl.cmp(3, i, a, 0, PRIM_STRIDE, b, 5, PRIM_STRIDE) for i in range(5)], dtype=np.int32)
+    adv = np.zeros((len(adversarial), 3, 64), dtype=np.int32)
+    for i, (p, q) in enumerate(adversarial):
+        for kind in range(3):
+            for part in range(64):
+                adv[i, kind, part] = impl.cmp(kind, part, p, 0, PRIM_STRIDE, q, 0, PRIM_STRIDE)
+    res["adv"] = adv
+    # sad_x3 / sad_x4 with the harness's odd reference stride 59 and refs at +0..+3
+    x3 = np.zeros((64, PRIM_ITERS, 3), dtype=np.int32)
+    x4 = np.zeros((64, PRIM_ITERS, 4), dtype=np.int32)
+    for part in range(64):
+        for it in range(PRIM_ITERS):
+            j = it * PRIM_INCR
+            x3[part, it] = impl.sad_xn(3, part, a, 0, b, [j, j + 1, j + 2], PRIM_STRIDE - 5)
+            x4[part, it] = impl.sad_xn(4, part, a, 0, b, [j, j + 1, j + 2, j + 3], PRIM_STRIDE - 5)
+    res["x3"] = x3
+    res["x4"] = x4
+    return res
+
+
+def run_ip_suite(impl, bits: int, depth: int) -> dict:
+    """impl.ipfilter_run(kind, src2d, x0, y0, w, h, frac, depth) -> 2-D output array"""
+    src, ssrc = ip_source(bits)
+    out = {}
+    for kind in range(4):
+        for frac in (1, 2, 3):
+            for (w, h) in IP_SIZES:
+                s = ssrc if kind == 3 else src
+                o = impl.ipfilter_run(kind, s, 8, 8, w, h, frac, depth)
+                out["k%d_f%d_%dx%d" % (kind, frac, w, h)] = np.ascontiguousarray(o)
+    return out

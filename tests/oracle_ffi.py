@@ -1,0 +1,205 @@
+"""ctypes bindings for the CHECKERS used by the tests:
+
+* ``Oracle``   -- oracle/libme_oracle.so, this repo's plain-C restatement (travels to the GPU box);
+* ``Reference``-- oracle/_ref/libx265ref{8,16}.so, the reference's own translation units compiled
+                  unmodified by oracle/Makefile (only exists where /root/reference was available
+                  at build time; the prebuilt .so travels, the sources do not).
+
+Test infrastructure only: nothing under x265_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libme_oracle.so")
+REF_SO = {8: os.path.join(ROOT, "oracle", "_ref", "libx265ref8.so"),
+          16: os.path.join(ROOT, "oracle", "_ref", "libx265ref16.so")}
+
+import sys
+sys.path.insert(0, ROOT)
+from x265_amd.jobs import JOB_DTYPE, RESULT_DTYPE  # noqa: E402
+from x265_amd.synth import MARGIN  # noqa: E402
+
+
+class MeoPlane(C.Structure):
+    _fields_ = [("pix", C.c_void_p), ("stride", C.c_ssize_t), ("bytes_per_px", C.c_int),
+                ("bit_depth", C.c_int), ("lowres", C.c_void_p * 4)]
+
+
+def plane_origin(padded: np.ndarray, margin: int = MARGIN) -> int:
+    """address of pixel (0,0) inside a padded plane"""
+    return padded.ctypes.data + (margin * padded.shape[1] + margin) * padded.itemsize
+
+
+def _ptr(a: np.ndarray, off_elems: int = 0) -> int:
+    return a.ctypes.data + off_elems * a.itemsize
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            raise FileNotFoundError(ORACLE_SO + " (run `make -C oracle oracle` or __graft_entry__.build())")
+        L = self.lib = C.CDLL(ORACLE_SO)
+        for suf in ("u8", "u16"):
+            f = getattr(L, "meo_cmp_" + suf)
+            f.restype = C.c_int
+            f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
+            f = getattr(L, "meo_sad_xn_" + suf)
+            f.restype = None
+            f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_ssize_t, C.c_void_p]
+            f = getattr(L, "meo_ipfilter_" + suf)
+            f.restype = None
+            f.argtypes = [C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.meo_mvcost_table.argtypes = [C.c_int, C.c_void_p]
+        L.meo_mvcost.restype = C.c_int
+        L.meo_bitcost.restype = C.c_int
+        L.meo_partition_from_sizes.restype = C.c_int
+        L.meo_search_batch.restype = C.c_int64
+        L.meo_search_batch.argtypes = [C.POINTER(MeoPlane), C.POINTER(MeoPlane), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.meo_buf_cost.restype = C.c_int
+        L.meo_buf_cost.argtypes = [C.POINTER(MeoPlane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
+        L.meo_lowres_core_u8.argtypes = [C.c_void_p] * 5 + [C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int]
+
+    @staticmethod
+    def _suf(a):
+        return "u8" if a.itemsize == 1 else "u16"
+
+    def cmp(self, kind, idx, fenc, fenc_off, fs, fref, fref_off, rs):
+        return getattr(self.lib, "meo_cmp_" + self._suf(fenc))(kind, idx, _ptr(fenc, fenc_off), fs, _ptr(fref, fref_off), rs)
+
+    def sad_xn(self, n, part, fenc, fenc_off, fref, fref_offs, rs):
+        ptrs = (C.c_void_p * n)(*[_ptr(fref, o) for o in fref_offs])
+        res = np.zeros(n, dtype=np.int32)
+        getattr(self.lib, "meo_sad_xn_" + self._suf(fenc))(n, part, _ptr(fenc, fenc_off), ptrs, rs, res.ctypes.data)
+        return res
+
+    def mvcost_table(self, qp):
+        out = np.zeros(65536, dtype=np.uint16)
+        self.lib.meo_mvcost_table(qp, out.ctypes.data)
+        return out
+
+    def ipfilter(self, kind, src, src_off, ss, dst, dst_off, ds, w, h, frac, depth, pix_itemsize):
+        suf = "u8" if pix_itemsize == 1 else "u16"
+        getattr(self.lib, "meo_ipfilter_" + suf)(kind, _ptr(src, src_off), ss, _ptr(dst, dst_off), ds, w, h, frac, depth)
+
+    @staticmethod
+    def make_plane(padded: np.ndarray, bit_depth=None, margin: int = MARGIN, lowres=None) -> MeoPlane:
+        p = MeoPlane()
+        p.pix = plane_origin(padded, margin)
+        p.stride = padded.shape[1]
+        p.bytes_per_px = padded.itemsize
+        p.bit_depth = bit_depth if bit_depth is not None else (8 if padded.itemsize == 1 else 10)
+        if lowres is not None:
+            for i in range(4):
+                p.lowres[i] = plane_origin(lowres[i], margin)
+        return p
+
+    def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN):
+        """returns (results, evals)"""
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        if not isinstance(ref_padded_list, (list, tuple)):
+            ref_padded_list = [ref_padded_list]
+        enc = self.make_plane(enc_padded, bit_depth, margin)
+        refs = (MeoPlane * len(ref_padded_list))(*[self.make_plane(r, bit_depth, margin) for r in ref_padded_list])
+        out = np.zeros(len(jobs), dtype=RESULT_DTYPE)
+        evals = self.lib.meo_search_batch(C.byref(enc), refs, jobs.ctypes.data, len(jobs), out.ctypes.data, threads)
+        return out, evals
+
+
+class Reference:
+    """The compiled reference (C primitives only, cpuid=1)."""
+
+    def __init__(self, bits: int = 8):
+        so = REF_SO[bits]
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        L = self.lib = C.CDLL(so)
+        self.bits = bits
+        L.ref_init()
+        assert L.ref_pixel_bytes() == bits // 8
+        L.ref_cmp.restype = C.c_int
+        L.ref_cmp.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
+        L.ref_sad_x3.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_ssize_t, C.c_void_p]
+        L.ref_sad_x4.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_ssize_t, C.c_void_p]
+        L.ref_ipfilter_pp.argtypes = [C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.ref_ipfilter_ps_h.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.ref_ipfilter_sp_v.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.ref_mvcost_table.argtypes = [C.c_int, C.c_void_p]
+        L.ref_mvcost.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+        L.ref_me_new.restype = C.c_void_p
+        L.ref_me_free.argtypes = [C.c_void_p]
+        L.ref_me_search.restype = C.c_int
+        L.ref_me_search.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_me_buf.restype = C.c_int
+        L.ref_me_buf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
+        L.ref_lowres_core.argtypes = [C.c_void_p] * 5 + [C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int]
+        self.me = L.ref_me_new()
+
+    def set_bit_depth(self, depth):
+        self.lib.ref_set_bit_depth(depth)
+
+    def cmp(self, kind, idx, fenc, fenc_off, fs, fref, fref_off, rs):
+        return self.lib.ref_cmp(kind, idx, _ptr(fenc, fenc_off), fs, _ptr(fref, fref_off), rs)
+
+    def sad_xn(self, n, part, fenc, fenc_off, fref, fref_offs, rs):
+        res = np.zeros(16, dtype=np.int32)
+        ptrs = [_ptr(fref, o) for o in fref_offs]
+        if n == 3:
+            self.lib.ref_sad_x3(part, _ptr(fenc, fenc_off), *ptrs, rs, res.ctypes.data)
+        else:
+            self.lib.ref_sad_x4(part, _ptr(fenc, fenc_off), *ptrs, rs, res.ctypes.data)
+        return res[:n].copy()
+
+    def mvcost_table(self, qp):
+        out = np.zeros(65536, dtype=np.uint16)
+        self.lib.ref_mvcost_table(qp, out.ctypes.data)
+        return out
+
+    def mvcost_bits(self, qp, mvp, mv):
+        a, b = C.c_int(), C.c_int()
+        self.lib.ref_mvcost(qp, mvp[0], mvp[1], mv[0], mv[1], C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def ipfilter(self, kind, src, src_off, ss, dst, dst_off, ds, w, h, frac):
+        if kind in (0, 1):
+            self.lib.ref_ipfilter_pp(kind, _ptr(src, src_off), ss, _ptr(dst, dst_off), ds, w, h, frac)
+        elif kind == 2:
+            self.lib.ref_ipfilter_ps_h(_ptr(src, src_off), ss, _ptr(dst, dst_off), ds, w, h, frac)
+        else:
+            self.lib.ref_ipfilter_sp_v(_ptr(src, src_off), ss, _ptr(dst, dst_off), ds, w, h, frac)
+
+    def search(self, enc_padded, ref_padded_list, jobs, margin: int = MARGIN):
+        """Runs every job through MotionEstimate::motionEstimate; returns RESULT_DTYPE array.
+        Jobs with icost != 0 have no reference counterpart and are rejected."""
+        if not isinstance(ref_padded_list, (list, tuple)):
+            ref_padded_list = [ref_padded_list]
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        out = np.zeros(len(jobs), dtype=RESULT_DTYPE)
+        enc0 = plane_origin(enc_padded, margin)
+        es = enc_padded.shape[1]
+        for i, j in enumerate(jobs):
+            assert j["icost"] == 0
+            ref = ref_padded_list[int(j["ref_idx"])]
+            assert ref.shape[1] == es, "the reference applies one blockOffset to both planes"
+            mvmin = np.array([j["mvmin_x"], j["mvmin_y"]], dtype=np.int16)
+            mvmax = np.array([j["mvmax_x"], j["mvmax_y"]], dtype=np.int16)
+            qmvp = np.array([j["qmvp_x"], j["qmvp_y"]], dtype=np.int16)
+            mvc = np.ascontiguousarray(j["mvc"], dtype=np.int16)
+            omv = np.zeros(2, dtype=np.int16)
+            cost = self.lib.ref_me_search(self.me, enc0, es, plane_origin(ref, margin), ref.shape[1], None,
+                                          int(j["pu_y"]) * es + int(j["pu_x"]), int(j["w"]), int(j["h"]),
+                                          mvmin.ctypes.data, mvmax.ctypes.data, qmvp.ctypes.data,
+                                          int(j["numc"]), mvc.ctypes.data, int(j["merange"]),
+                                          int(j["method"]), int(j["subme"]), int(j["qp"]), omv.ctypes.data)
+            out[i] = (omv[0], omv[1], cost)
+        return out
+
+
+def have_reference(bits: int = 8) -> bool:
+    return os.path.exists(REF_SO[bits])

@@ -1,0 +1,77 @@
+"""CPU restatement (oracle/libme_oracle.so) against the golden vectors that were generated from
+the compiled reference (oracle/gen_golden.py).  This is the pin that lets the restatement act
+as the checker on the GPU box, where the reference itself is absent."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+
+
+def _load(name):
+    return np.load(os.path.join(G.GOLDEN_DIR, name), allow_pickle=False)
+
+
+class OracleIp:
+    def __init__(self, oracle, bits):
+        self.o, self.bits = oracle, bits
+
+    def ipfilter_run(self, kind, src, x0, y0, w, h, frac, depth):
+        pdt = np.uint8 if self.bits == 8 else np.uint16
+        dst = np.zeros((h, w), dtype=np.int16 if kind == 2 else pdt)
+        ss = src.shape[1]
+        self.o.ipfilter(kind, src, y0 * ss + x0, ss, dst, 0, w, w, h, frac, depth, self.bits // 8)
+        return dst
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_primitives_match_reference_vectors(oracle, bits):
+    gold = _load("prim_u%d.npz" % bits)
+    got = G.run_prim_suite(oracle, bits)
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), k
+
+
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 8), (16, 10)])
+def test_interpolation_matches_reference_vectors(oracle, bits, depth):
+    gold = _load("ipfilter_u%d_d%d.npz" % (bits, depth))
+    got = G.run_ip_suite(OracleIp(oracle, bits), bits, depth)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), k
+
+
+def test_mvcost_tables_match_reference_vectors(oracle):
+    gold = _load("mvcost.npz")
+    for qp in G.MV_QPS:
+        t = oracle.mvcost_table(qp)
+        # entry 0 (MVD -32768) is never written by the reference (bitcost.cpp:52-56)
+        assert np.array_equal(t[1:], gold["qp%d" % qp][1:]), qp
+    for p, m, (c, b) in zip(gold["bc_mvp"].tolist(), gold["bc_mv"].tolist(), gold["bc_out"].tolist()):
+        assert oracle.lib.meo_mvcost(32, p[0], p[1], m[0], m[1]) == c
+        assert oracle.lib.meo_bitcost(p[0], p[1], m[0], m[1]) == b
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_search_matches_reference_vectors(oracle, bits):
+    gold = _load("search_u%d.npz" % bits)
+    jobs = G.search_jobs(bits)
+    assert zlib.crc32(jobs.tobytes()) == int(gold["jobs_crc"][0])
+    for kind in ("motion", "noise"):
+        fr = G.search_frames(bits, kind)
+        got, evals = oracle.search(fr[0], [fr[1], fr[2]], jobs, threads=4, bit_depth=8 if bits == 8 else 10)
+        exp = gold["res_" + kind]
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (kind, jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+        assert evals > 0
+
+
+def test_full_search_field_matches_reference_vectors(oracle):
+    gold = _load("field_full.npz")
+    jobs = G.field_jobs()
+    assert zlib.crc32(jobs.tobytes()) == int(gold["jobs_crc"][0])
+    fr = G.field_frames()
+    got, _ = oracle.search(fr[0], [fr[1]], jobs, threads=4)
+    assert np.array_equal(got, gold["res"])

@@ -1,0 +1,39 @@
+"""Randomised differential test: CPU restatement vs the compiled reference (oracle/_ref).
+Skipped where the reference build is absent."""
+import numpy as np
+import pytest
+
+from oracle_ffi import Reference, have_reference
+from x265_amd import jobs as J
+from x265_amd import synth
+
+pytestmark = pytest.mark.skipif(not have_reference(8), reason="oracle/_ref not built (no /root/reference)")
+
+
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10)])
+def test_random_jobs(oracle, bits, depth):
+    ref = Reference(bits)
+    ref.set_bit_depth(depth)
+    W, H = 352, 288
+    rng = np.random.default_rng(123 + bits)
+    for kind in ("motion", "noise"):
+        fr = synth.make_sequence(W, H, 2, seed=31 + bits, bit_depth=depth if bits == 16 else 8, kind=kind)
+        parts = []
+        for _ in range(150):
+            w, h = int(rng.choice(J.DIMS)), int(rng.choice(J.DIMS))
+            method = int(rng.integers(0, 5))
+            if method == J.UMH and w == 4 and h == 4:
+                continue
+            merange = int(rng.integers(4, 20)) if method == J.FULL else int(rng.integers(4, 70))
+            px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            k = int(rng.integers(0, 5))
+            mvc = rng.integers(-300, 300, (k, 2)) if k else None
+            parts.append(J.make_jobs(W, H, [px], [py], w, h, method=method, subme=int(rng.integers(0, 8)),
+                                     merange=merange, qp=int(rng.integers(0, 52)),
+                                     qmvp=(int(rng.integers(-250, 250)), int(rng.integers(-250, 250))), mvc=mvc))
+        jobs = np.concatenate(parts)
+        a, _ = oracle.search(fr[0], [fr[1]], jobs, threads=2, bit_depth=depth)
+        b = ref.search(fr[0], [fr[1]], jobs)
+        bad = np.nonzero(a != b)[0]
+        assert bad.size == 0, (jobs[bad[:2]], a[bad[:2]], b[bad[:2]])
