@@ -1,0 +1,178 @@
+/* x265_amd -- MI355X (gfx950) motion-estimation engine: C ABI.
+ *
+ * This is the drop-in boundary for the motion-estimation hot path of x265.  Every entry
+ * point names the reference interface it stands in for (paths relative to the reference's
+ * source/ directory).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * All compute entry points run hand-written HIP kernels on the GPU.  There is no CPU
+ * fallback: every call returns X265AMD_ERR_NO_DEVICE / a HIP error code when the device or
+ * the kernels are unavailable.
+ *
+ * Threading: a context owns one HIP stream.  Calls on one context are serialised by an
+ * internal mutex; use one context per host thread for concurrency (the reference uses one
+ * MotionEstimate per CTU row, encoder/cturow.h:56).
+ */
+#ifndef X265_AMD_H
+#define X265_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265AMD_MAX_MVC     4     /* candidates per job (lookahead passes at most 4: encoder/slicetype.cpp:382) */
+#define X265AMD_MAX_REFS    16    /* reference planes addressable by one batch */
+#define X265AMD_FENC_STRIDE 64    /* common/primitives.h:34 */
+
+/* error codes (negative).  The reference has no error convention for this path
+ * (int/void returns and assert(), common/primitives.cpp:49-50); batch calls here return 0 or: */
+enum
+{
+    X265AMD_OK             = 0,
+    X265AMD_ERR_NO_DEVICE  = -1,   /* no HIP device / kernels not loadable */
+    X265AMD_ERR_INVALID    = -2,   /* bad argument (size not a partition, plane id, qp, ...) */
+    X265AMD_ERR_NOMEM      = -3,
+    X265AMD_ERR_HIP        = -4,   /* a HIP runtime call failed; see x265amd_last_error() */
+    X265AMD_ERR_RANGE      = -5    /* a job's search window reaches outside the registered plane margins */
+};
+
+/* cost kinds: EncoderPrimitives::sad / satd / sa8d_inter (common/primitives.h:242-249) */
+enum { X265AMD_SAD = 0, X265AMD_SATD = 1, X265AMD_SA8D = 2 };
+
+/* search methods: X265_DIA_SEARCH .. X265_FULL_SEARCH (x265.h, --me 0..4) */
+enum { X265AMD_DIA = 0, X265AMD_HEX = 1, X265AMD_UMH = 2, X265AMD_STAR = 3, X265AMD_FULL = 4 };
+
+typedef struct x265amd_ctx x265amd_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (one stream, MV-cost tables built lazily per QP as
+ * BitCost::setQP does, encoder/bitcost.cpp:35-61). */
+int  x265amd_create(int device, x265amd_ctx **out);
+void x265amd_destroy(x265amd_ctx *ctx);
+/* text of the last error on this context (never NULL) */
+const char *x265amd_last_error(const x265amd_ctx *ctx);
+/* wait for all work queued on the context's stream */
+int  x265amd_sync(x265amd_ctx *ctx);
+/* the hipStream_t the context launches on (for callers that time or order against it) */
+void *x265amd_stream(x265amd_ctx *ctx);
+
+/* ---- planes --------------------------------------------------------------------------
+ * A plane is a border-extended luma picture as TComPicYuv lays it out
+ * (Lib/TLibCommon/TComPicYuv.cpp:68-120): `base` is the first byte of the padded
+ * allocation, pixel (0,0) sits at base + (margin_y*stride + margin_x) pixels, stride in
+ * pixels.  This is what ReferencePlanes::fpelPlane / lumaStride (common/reference.h:36-53)
+ * and MotionEstimate::setSourcePlane (encoder/motion.h:78-82) carry. */
+
+/* copy a host plane to the device (H2D on the context's stream); borrowed only during the call */
+int x265amd_plane_upload(x265amd_ctx *ctx, const void *host_base, int width, int height,
+                         int margin_x, int margin_y, intptr_t stride, int bytes_per_px, int bit_depth,
+                         int *plane_id);
+/* wrap a plane that already lives in device memory (e.g. filled by an RCCL broadcast);
+ * the memory is borrowed until x265amd_plane_release */
+int x265amd_plane_wrap_device(x265amd_ctx *ctx, void *dev_base, int width, int height,
+                              int margin_x, int margin_y, intptr_t stride, int bytes_per_px, int bit_depth,
+                              int *plane_id);
+/* device address of the padded allocation of a plane (upload target / broadcast buffer) */
+void *x265amd_plane_device_ptr(x265amd_ctx *ctx, int plane_id);
+int x265amd_plane_release(x265amd_ctx *ctx, int plane_id);
+
+/* ---- batched block costs -------------------------------------------------------------
+ * n independent evaluations of EncoderPrimitives::sad / satd / sa8d_inter
+ * [PartitionFromSizes(w,h)] (common/primitives.h:242-249, common/pixel.cpp:645-826):
+ * out[i] = cost(enc block at (enc_x,enc_y), ref block at (ref_x,ref_y)). */
+typedef struct x265amd_block_pair
+{
+    int32_t enc_plane, enc_x, enc_y;
+    int32_t ref_plane, ref_x, ref_y;
+} x265amd_block_pair;
+
+int x265amd_cost_batch(x265amd_ctx *ctx, int kind, int w, int h, int n,
+                       const x265amd_block_pair *pairs, int32_t *out);
+
+/* ---- batched motion search ------------------------------------------------------------
+ * One job == one MotionEstimate::motionEstimate call (encoder/motion.h:95,
+ * encoder/motion.cpp:277-866) preceded by setQP / setSearchMethod / setSubpelRefine /
+ * setSourcePU (encoder/motion.h:72-84).  (pu_x,pu_y) replaces the reference's linear
+ * `offset` argument: offset = pu_y*stride + pu_x. */
+typedef struct x265amd_me_job
+{
+    int32_t pu_x, pu_y;
+    int16_t w, h;                       /* each in {4,8,12,16,24,32,48,64} */
+    int16_t mvmin_x, mvmin_y;           /* full-pel, inclusive (const MV& mvmin) */
+    int16_t mvmax_x, mvmax_y;
+    int16_t qmvp_x, qmvp_y;             /* q-pel predictor (const MV& qmvp) */
+    int16_t merange;
+    uint8_t method;                     /* X265AMD_DIA .. X265AMD_FULL */
+    uint8_t subme;                      /* 0..7, workload[] of encoder/motion.cpp:51-60 */
+    uint8_t qp;                         /* 0..51 */
+    uint8_t numc;                       /* numCandidates, <= X265AMD_MAX_MVC */
+    uint8_t ref_idx;                    /* index into the batch's ref_planes[] */
+    uint8_t icost;                      /* integer-stage cost kind: X265AMD_SAD is the reference's
+                                           behaviour; SATD / SA8D are extensions */
+    int16_t mvc[X265AMD_MAX_MVC][2];    /* q-pel candidates (const MV* mvc) */
+} x265amd_me_job;
+
+typedef struct x265amd_me_result
+{
+    int16_t mvx, mvy;                   /* outQMv, q-pel */
+    int32_t cost;                       /* return value of motionEstimate() */
+} x265amd_me_result;
+
+/* jobs / out in host memory; blocks until the results are in `out` */
+int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
+                            const x265amd_me_job *jobs, int n, x265amd_me_result *out);
+
+/* jobs / out already in device memory; asynchronous on the context's stream.
+ * The caller guarantees the buffers stay valid until x265amd_sync(). */
+int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
+                                   const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
+
+/* number of block-cost evaluations executed by the search kernels since the counter was last
+ * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */
+int x265amd_eval_count(x265amd_ctx *ctx, int reset, uint64_t *evals);
+
+/* MV-cost model (encoder/bitcost.h:43-53, encoder/bitcost.cpp:35-85) */
+/* out[i + 32768] = BitCost::s_costs[qp][i], i in [-32767, 32767]; out[0] = 0 */
+int x265amd_mvcost_table(x265amd_ctx *ctx, int qp, uint16_t *out65536);
+/* BitCost::bitcost(mv) for predictor mvp (all q-pel) */
+int x265amd_bitcost(x265amd_ctx *ctx, int mvp_x, int mvp_y, int mv_x, int mv_y);
+
+/* ---- per-call primitives ---------------------------------------------------------------
+ * Functions with the exact signatures of the reference's primitive table
+ * (pixelcmp_t / pixelcmp_x3_t / pixelcmp_x4_t, common/primitives.h:180-184) operating on HOST
+ * pointers.  `pixel` is uint8_t in the 8-bit table and uint16_t in the 16-bit table.  Each
+ * call stages its blocks to the GPU, runs the cost kernel and returns the result, so that
+ * the reference's own TestBench recipe (test/pixelharness.cpp) can be replayed; the batched
+ * calls above are the performance path.  They use a process-wide context created by
+ * x265amd_setup_primitives(). */
+typedef int  (*x265amd_pixelcmp_t)(void *fenc, intptr_t fencstride, void *fref, intptr_t frefstride);
+typedef void (*x265amd_pixelcmp_x3_t)(void *fenc, void *fref0, void *fref1, void *fref2, intptr_t frefstride, int *res);
+typedef void (*x265amd_pixelcmp_x4_t)(void *fenc, void *fref0, void *fref1, void *fref2, void *fref3, intptr_t frefstride, int *res);
+
+/* The slice of EncoderPrimitives (common/primitives.h:240-250) this library provides;
+ * indices are the Partitions / SquareBlocks enums (common/primitives.h:77-98). */
+typedef struct x265amd_primitives
+{
+    x265amd_pixelcmp_t    sad[64];
+    x265amd_pixelcmp_x3_t sad_x3[64];
+    x265amd_pixelcmp_x4_t sad_x4[64];
+    x265amd_pixelcmp_t    satd[64];
+    x265amd_pixelcmp_t    sa8d_inter[64];
+    x265amd_pixelcmp_t    sa8d[5];
+} x265amd_primitives;
+
+/* Fill `p` the way Setup_Vector_Primitives / Setup_Assembly_Primitives overwrite slots of
+ * x265::primitives (common/primitives.cpp:129-139).  bytes_per_px selects the pixel type
+ * (1: HIGH_BIT_DEPTH=0, 2: HIGH_BIT_DEPTH=1). */
+int x265amd_setup_primitives(x265amd_primitives *p, int device, int bytes_per_px);
+
+/* PartitionFromSizes (common/primitives.cpp:40-54); -1 if not a partition */
+int x265amd_partition_from_sizes(int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_AMD_H */

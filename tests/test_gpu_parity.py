@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against
+(a) the golden vectors generated from the compiled reference and
+(b) the CPU restatement (oracle) on seeded inputs.
+Bit-exact: integer costs and MVs must be identical."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from x265_amd import jobs as J
+from x265_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from x265_amd.api import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _load(name):
+    return np.load(os.path.join(G.GOLDEN_DIR, name), allow_pickle=False)
+
+
+class PrimAdapter:
+    """Drives the per-call primitive table (reference signatures, host pointers)."""
+
+    def __init__(self, bits):
+        from x265_amd.api import setup_primitives
+        self.p = setup_primitives(0, bits // 8)
+
+    def cmp(self, kind, idx, fenc, fenc_off, fs, fref, fref_off, rs):
+        a = fenc.ctypes.data + fenc_off * fenc.itemsize
+        b = fref.ctypes.data + fref_off * fref.itemsize
+        tab = (self.p.sad, self.p.satd, self.p.sa8d_inter, self.p.sa8d)[kind]
+        return tab[idx](a, fs, b, rs)
+
+    def sad_xn(self, n, part, fenc, fenc_off, fref, fref_offs, rs):
+        res = (C.c_int * 16)()
+        a = fenc.ctypes.data + fenc_off * fenc.itemsize
+        ptrs = [fref.ctypes.data + o * fref.itemsize for o in fref_offs]
+        if n == 3:
+            self.p.sad_x3[part](a, *ptrs, rs, C.addressof(res))
+        else:
+            self.p.sad_x4[part](a, *ptrs, rs, C.addressof(res))
+        return np.array(res[:n], dtype=np.int32)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_primitive_table_matches_reference_vectors(bits):
+    """The reference's TestBench recipe (test/pixelharness.cpp) replayed through the table."""
+    gold = _load("prim_u%d.npz" % bits)
+    got = G.run_prim_suite(PrimAdapter(bits), bits)
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), k
+
+
+def test_mvcost_tables_match_reference_vectors(eng):
+    gold = _load("mvcost.npz")
+    for qp in G.MV_QPS:
+        assert np.array_equal(eng.mvcost_table(qp)[1:], gold["qp%d" % qp][1:]), qp
+    for p, m, (c, b) in zip(gold["bc_mvp"].tolist(), gold["bc_mv"].tolist(), gold["bc_out"].tolist()):
+        assert eng.bitcost(p, m) == b
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_search_matches_reference_vectors(eng, bits):
+    gold = _load("search_u%d.npz" % bits)
+    jobs = G.search_jobs(bits)
+    assert zlib.crc32(jobs.tobytes()) == int(gold["jobs_crc"][0])
+    for kind in ("motion", "noise"):
+        fr = G.search_frames(bits, kind)
+        depth = 8 if bits == 8 else 10
+        ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+        got = eng.search(ids[0], [ids[1], ids[2]], jobs)
+        for i in ids:
+            eng.release_plane(i)
+        exp = gold["res_" + kind]
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (kind, len(bad), jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+
+
+def test_full_search_field_matches_reference_vectors(eng):
+    gold = _load("field_full.npz")
+    jobs = G.field_jobs()
+    fr = G.field_frames()
+    ids = [eng.upload_plane(f) for f in fr]
+    got = eng.search(ids[0], [ids[1]], jobs)
+    for i in ids:
+        eng.release_plane(i)
+    bad = np.nonzero(got != gold["res"])[0]
+    assert bad.size == 0, (len(bad), jobs[bad[:3]], got[bad[:3]], gold["res"][bad[:3]])
+
+
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10), (16, 8)])
+def test_random_jobs_match_oracle(eng, oracle, bits, depth):
+    """Randomised jobs (all methods, sub-pel levels, partitions, extension cost kinds)."""
+    W, H = 352, 288
+    rng = np.random.default_rng(555 + bits + depth)
+    for kind in ("motion", "noise"):
+        fr = synth.make_sequence(W, H, 2, seed=91 + bits, bit_depth=depth if bits == 16 else 8, kind=kind)
+        parts = []
+        for _ in range(400):
+            w, h = int(rng.choice(J.DIMS)), int(rng.choice(J.DIMS))
+            method = int(rng.integers(0, 5))
+            if method == J.UMH and w == 4 and h == 4:
+                continue
+            merange = int(rng.integers(2, 20)) if method == J.FULL else int(rng.integers(2, 70))
+            px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            k = int(rng.integers(0, 5))
+            mvc = rng.integers(-300, 300, (k, 2)) if k else None
+            icost = int(rng.choice([0, 0, 0, 1, 2]))
+            parts.append(J.make_jobs(W, H, [px], [py], w, h, method=method, subme=int(rng.integers(0, 8)),
+                                     merange=merange, qp=int(rng.integers(0, 52)),
+                                     qmvp=(int(rng.integers(-250, 250)), int(rng.integers(-250, 250))), mvc=mvc,
+                                     icost=icost))
+        jobs = np.concatenate(parts)
+        exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+        ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+        eng.eval_count(reset=True)
+        got = eng.search(ids[0], [ids[1]], jobs)
+        gpu_evals = eng.eval_count()
+        for i in ids:
+            eng.release_plane(i)
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (kind, len(bad), jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+        assert gpu_evals == evals, (gpu_evals, evals)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_cost_batch_matches_oracle(eng, oracle, bits):
+    """Batched sad / satd / sa8d_inter on plane-resident blocks, incl. blocks in the padded border."""
+    W, H = 320, 192
+    depth = 8 if bits == 8 else 10
+    fr = synth.make_sequence(W, H, 2, seed=5 + bits, bit_depth=depth, kind="noise")
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    rng = np.random.default_rng(bits)
+    M = synth.MARGIN
+    stride = fr[0].shape[1]
+    from x265_amd.api import PAIR_DTYPE
+    for kind in (0, 1, 2):
+        for (w, h) in ((4, 4), (8, 8), (16, 16), (64, 64), (12, 16), (24, 32), (48, 64), (64, 16), (8, 4), (32, 24), (16, 8)):
+            n = 40
+            pairs = np.zeros(n, dtype=PAIR_DTYPE)
+            pairs["enc_plane"] = ids[0]
+            pairs["ref_plane"] = ids[1]
+            pairs["enc_x"] = rng.integers(-M, W + M - w + 1, n)
+            pairs["enc_y"] = rng.integers(-M, H + M - h + 1, n)
+            pairs["ref_x"] = rng.integers(-M, W + M - w + 1, n)
+            pairs["ref_y"] = rng.integers(-M, H + M - h + 1, n)
+            pairs[0] = (ids[0], -M, -M, ids[1], W + M - w, H + M - h)     # extreme corners
+            got = eng.cost_batch(kind, w, h, pairs)
+            part = J.partition_from_sizes(w, h)
+            for i in range(n):
+                eo = (int(pairs["enc_y"][i]) + M) * stride + int(pairs["enc_x"][i]) + M
+                ro = (int(pairs["ref_y"][i]) + M) * stride + int(pairs["ref_x"][i]) + M
+                exp = oracle.cmp(kind, part, fr[0].reshape(-1), eo, stride, fr[1].reshape(-1), ro, stride)
+                assert got[i] == exp, (kind, w, h, i, got[i], exp)
+    for i in ids:
+        eng.release_plane(i)
+
+
+def test_full_search_properties_at_full_size(eng, oracle):
+    """1080p, FULL +-64: size-independent checks -- (1) a planted pure translation is found with
+    SAD 0, (2) the winner's cost is reproduced by the batched SAD primitive + mvcost, (3) a sample
+    of PUs equals the oracle."""
+    W, H = 1920, 1080
+    base = synth.base_frame(W, H, seed=99)
+    shift = (7, -5)
+    ref_img = np.roll(base, (-shift[1], -shift[0]), axis=(0, 1))   # ref(x,y) = enc(x - sx, y - sy)... planted MV = shift
+    enc = synth.pad_plane(base)
+    ref = synth.pad_plane(ref_img)
+    ids = [eng.upload_plane(enc), eng.upload_plane(ref)]
+    jobs = J.frame_jobs(W, H, sizes=(64, 16), method=J.FULL, subme=0, merange=64, qp=32)
+    # interior PUs only (np.roll wraps at the borders)
+    keep = (jobs["pu_x"] >= 128) & (jobs["pu_x"] + jobs["w"] <= W - 128) & (jobs["pu_y"] >= 128) & (jobs["pu_y"] + jobs["h"] <= H - 128)
+    jobs = jobs[keep][::7]
+    got = eng.search(ids[0], [ids[1]], jobs)
+    # enc(x,y) == ref(x - sx, y - sy) -> best MV = (-sx, -sy) full-pel, SATD 0, cost = mvcost only
+    tab = eng.mvcost_table(32).astype(np.int64)
+    expect_cost = tab[32768 + (-shift[0] * 4)] + tab[32768 + (-shift[1] * 4)]
+    assert np.all(got["mvx"] == -shift[0] * 4) and np.all(got["mvy"] == -shift[1] * 4)
+    assert np.all(got["cost"] == expect_cost)
+    sample = jobs[:: max(1, len(jobs) // 12)]
+    exp, _ = oracle.search(enc, [ref], sample, threads=8)
+    got_s = eng.search(ids[0], [ids[1]], sample)
+    assert np.array_equal(exp, got_s)
+    for i in ids:
+        eng.release_plane(i)
+
+
+def test_errors_are_reported(eng):
+    fr = synth.make_sequence(64, 64, 2, seed=1)
+    ids = [eng.upload_plane(f) for f in fr]
+    from x265_amd.api import X265AmdError
+    bad = J.make_jobs(64, 64, [0], [0], 16, 16, method=J.HEX, subme=1, merange=8, qp=30)
+    bad["w"] = 20
+    with pytest.raises(X265AmdError):
+        eng.search(ids[0], [ids[1]], bad)
+    ok = J.make_jobs(64, 64, [0], [0], 16, 16, method=J.HEX, subme=1, merange=8, qp=30)
+    with pytest.raises(X265AmdError):
+        eng.search(ids[0], [99], ok)
+    empty = eng.search(ids[0], [ids[1]], ok[:0])
+    assert len(empty) == 0
+    for i in ids:
+        eng.release_plane(i)

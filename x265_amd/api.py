@@ -1,0 +1,175 @@
+"""ctypes binding of the x265_amd C ABI (include/x265_amd.h) plus thin host-side helpers.
+
+The library is the product: every compute call below runs HIP kernels on an MI355X.  If the
+shared library or the GPU is missing this module raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .jobs import JOB_DTYPE, RESULT_DTYPE
+from .synth import MARGIN
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx265amd.so")
+
+SAD, SATD, SA8D = 0, 1, 2
+
+PAIR_DTYPE = np.dtype([("enc_plane", "<i4"), ("enc_x", "<i4"), ("enc_y", "<i4"),
+                       ("ref_plane", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4")], align=True)
+
+PIXELCMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t)
+PIXELCMP_X3 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+PIXELCMP_X4 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+
+
+class Primitives(C.Structure):
+    """x265amd_primitives: the slice of EncoderPrimitives this library fills."""
+    _fields_ = [("sad", PIXELCMP * 64), ("sad_x3", PIXELCMP_X3 * 64), ("sad_x4", PIXELCMP_X4 * 64),
+                ("satd", PIXELCMP * 64), ("sa8d_inter", PIXELCMP * 64), ("sa8d", PIXELCMP * 5)]
+
+
+class X265AmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libx265amd.so; raises if it has not been built (see x265_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise X265AmdError("%s is missing: build it with `python -m x265_amd.build` "
+                           "(the HIP kernels are the only compute path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
+    L.x265amd_create.argtypes = [ci, C.POINTER(vp)]
+    L.x265amd_destroy.argtypes = [vp]
+    L.x265amd_destroy.restype = None
+    L.x265amd_last_error.argtypes = [vp]
+    L.x265amd_last_error.restype = C.c_char_p
+    L.x265amd_sync.argtypes = [vp]
+    L.x265amd_stream.argtypes = [vp]
+    L.x265amd_stream.restype = vp
+    plane_args = [vp, vp, ci, ci, ci, ci, C.c_ssize_t, ci, ci, cip]
+    L.x265amd_plane_upload.argtypes = plane_args
+    L.x265amd_plane_wrap_device.argtypes = plane_args
+    L.x265amd_plane_device_ptr.argtypes = [vp, ci]
+    L.x265amd_plane_device_ptr.restype = vp
+    L.x265amd_plane_release.argtypes = [vp, ci]
+    L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
+    L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
+    L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
+    L.x265amd_mvcost_table.argtypes = [vp, ci, vp]
+    L.x265amd_bitcost.argtypes = [vp, ci, ci, ci, ci]
+    L.x265amd_setup_primitives.argtypes = [C.POINTER(Primitives), ci, ci]
+    L.x265amd_partition_from_sizes.argtypes = [ci, ci]
+    _lib = L
+    return L
+
+
+class Engine:
+    """One x265amd context (one HIP stream on one device)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.x265amd_create(device, C.byref(h))
+        if rc != 0:
+            raise X265AmdError("x265amd_create(device=%d) failed with %d (no MI355X visible or kernels not loadable)" % (device, rc))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.x265amd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise X265AmdError("x265amd error %d: %s" % (rc, self.lib.x265amd_last_error(self.h).decode()))
+
+    @property
+    def stream(self) -> int:
+        return self.lib.x265amd_stream(self.h)
+
+    def sync(self):
+        self._chk(self.lib.x265amd_sync(self.h))
+
+    # -- planes ------------------------------------------------------------------------------
+    def upload_plane(self, padded: np.ndarray, bit_depth=None, margin: int = MARGIN) -> int:
+        """padded: (H + 2*margin, W + 2*margin) uint8/uint16 array with replicated borders"""
+        assert padded.flags["C_CONTIGUOUS"] and padded.dtype in (np.uint8, np.uint16)
+        hh, ww = padded.shape
+        pid = C.c_int(-1)
+        depth = bit_depth if bit_depth is not None else (8 if padded.itemsize == 1 else 10)
+        self._chk(self.lib.x265amd_plane_upload(self.h, padded.ctypes.data, ww - 2 * margin, hh - 2 * margin,
+                                                margin, margin, ww, padded.itemsize, depth, C.byref(pid)))
+        return pid.value
+
+    def wrap_device_plane(self, dev_ptr: int, width: int, height: int, stride: int, bytes_per_px: int,
+                          bit_depth: int, margin: int = MARGIN) -> int:
+        pid = C.c_int(-1)
+        self._chk(self.lib.x265amd_plane_wrap_device(self.h, dev_ptr, width, height, margin, margin, stride,
+                                                     bytes_per_px, bit_depth, C.byref(pid)))
+        return pid.value
+
+    def release_plane(self, pid: int):
+        self._chk(self.lib.x265amd_plane_release(self.h, pid))
+
+    # -- costs --------------------------------------------------------------------------------
+    def cost_batch(self, kind: int, w: int, h: int, pairs: np.ndarray) -> np.ndarray:
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        out = np.zeros(len(pairs), dtype=np.int32)
+        self._chk(self.lib.x265amd_cost_batch(self.h, kind, w, h, len(pairs), pairs.ctypes.data, out.ctypes.data))
+        return out
+
+    # -- search -------------------------------------------------------------------------------
+    def search(self, enc_plane: int, ref_planes, jobs: np.ndarray) -> np.ndarray:
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        refs = (C.c_int * len(ref_planes))(*ref_planes)
+        out = np.zeros(len(jobs), dtype=RESULT_DTYPE)
+        self._chk(self.lib.x265amd_me_search_batch(self.h, enc_plane, refs, len(ref_planes), jobs.ctypes.data,
+                                                   len(jobs), out.ctypes.data))
+        return out
+
+    def search_device(self, enc_plane: int, ref_planes, d_jobs_ptr: int, n: int, d_out_ptr: int):
+        """asynchronous: jobs/results are device pointers; call sync() before reading results"""
+        refs = (C.c_int * len(ref_planes))(*ref_planes)
+        self._chk(self.lib.x265amd_me_search_batch_device(self.h, enc_plane, refs, len(ref_planes), d_jobs_ptr, n, d_out_ptr))
+
+    def eval_count(self, reset: bool = False) -> int:
+        v = C.c_uint64(0)
+        self._chk(self.lib.x265amd_eval_count(self.h, int(reset), C.byref(v)))
+        return v.value
+
+    def mvcost_table(self, qp: int) -> np.ndarray:
+        out = np.zeros(65536, dtype=np.uint16)
+        self._chk(self.lib.x265amd_mvcost_table(self.h, qp, out.ctypes.data))
+        return out
+
+    def bitcost(self, mvp, mv) -> int:
+        return self.lib.x265amd_bitcost(self.h, mvp[0], mvp[1], mv[0], mv[1])
+
+
+def setup_primitives(device: int = 0, bytes_per_px: int = 1) -> Primitives:
+    """x265amd_setup_primitives: table of per-call primitives with the reference's signatures."""
+    lib = load_library()
+    p = Primitives()
+    rc = lib.x265amd_setup_primitives(C.byref(p), device, bytes_per_px)
+    if rc != 0:
+        raise X265AmdError("x265amd_setup_primitives failed with %d" % rc)
+    return p

@@ -1,0 +1,680 @@
+// MotionEstimate::motionEstimate as wave-uniform control flow over the wave-cooperative
+// cost functions of me_device.h.
+//
+// Reference: encoder/motion.cpp:277-866 (search), :868-1108 (StarPatternSearch),
+// :1110-1191 (subpelCompare / subpelInterpolate).  Every comparison is a strict `<` in the
+// reference's program order (common/common.h:71-92), so ties resolve identically.  The
+// reference's packed direction tags in DIA / HEX (motion.cpp:349-365, 393-424) are
+// order-equivalent to tracking the index of the last strict improvement.
+#pragma once
+
+#include "me_device.h"
+
+namespace xa {
+
+// result of the dedicated exhaustive-search kernel for one job (raster-order first minimum)
+struct FullBest
+{
+    int32_t cost;       // SAD + mvcost of the best raster candidate; INT32_MAX if none
+    int16_t mvx, mvy;   // full-pel
+};
+
+__constant__ int8_t c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__constant__ int8_t c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__constant__ int8_t c_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                      { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+__constant__ int8_t c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                              { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+// workload[] (motion.cpp:51-60): hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd
+__constant__ int8_t c_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                         { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+__constant__ uint8_t c_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+
+#define XA_S16(v) ((int)(int16_t)(v))
+
+template <typename PIX>
+struct Search
+{
+    Wave<PIX> &W;
+    const x265amd_me_job &j;
+    int bmx, bmy, bcost;
+
+    __device__ Search(Wave<PIX> &w_, const x265amd_me_job &j_) : W(w_), j(j_) {}
+
+    __device__ __forceinline__ bool in_range(int x, int y) const   // MV::checkRange, common/mv.h:96-99
+    {
+        return x >= j.mvmin_x && x <= j.mvmax_x && y >= j.mvmin_y && y <= j.mvmax_y;
+    }
+
+    // strict-less update with a candidate labelled (lx,ly)
+    __device__ __forceinline__ bool take(int c, int lx, int ly)
+    {
+        if (c < bcost)
+        {
+            bcost = c;
+            bmx = XA_S16(lx);
+            bmy = XA_S16(ly);
+            return true;
+        }
+        return false;
+    }
+
+    __device__ __forceinline__ int mvcost_fpel(int mx, int my) const
+    {
+        return W.mvcost(XA_S16(XA_S16(mx) << 2), XA_S16(XA_S16(my) << 2));
+    }
+
+    // COST_MV (motion.cpp:173-179)
+    __device__ void try_mv(int mx, int my)
+    {
+        take(W.cost_fpel(mx, my), mx, my);
+    }
+
+    // N candidates measured at (sx,sy)[k], labelled and priced as (lx,ly)[k], taken in order
+    template <int N>
+    __device__ int try_points(const int *sx, const int *sy, const int *lx, const int *ly)
+    {
+        int c[N], last = -1;
+        W.template icost_points<N>(sx, sy, c);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            if (take(c[k] + mvcost_fpel(lx[k], ly[k]), lx[k], ly[k]))
+                last = k;
+        return last;
+    }
+
+    // N candidates (cx,cy) + d[k], all relative to one centre, in order; returns index of the last taken or -1.
+    // Only the cost is updated; the caller moves bmv (pattern loops move after the whole set).
+    template <int N>
+    __device__ int probe(int cx, int cy, const int8_t (*d)[2])
+    {
+        int x[N], y[N], c[N], last = -1;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            x[k] = XA_S16(cx + d[k][0]);
+            y[k] = XA_S16(cy + d[k][1]);
+        }
+        W.template icost_points<N>(x, y, c);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            int cc = c[k] + mvcost_fpel(x[k], y[k]);
+            if (cc < bcost)
+            {
+                bcost = cc;
+                last = k;
+            }
+        }
+        return last;
+    }
+
+    // ---------------------------------------------------------------- STAR (motion.cpp:868-1108)
+    __device__ void pt(int mx, int my, int point, int dist, int &bPointNr, int &bDistance)
+    {
+        if (take(W.cost_fpel(mx, my), mx, my))
+        {
+            bPointNr = point;
+            bDistance = dist;
+        }
+    }
+
+    template <int N>
+    __device__ void pts(const int *x, const int *y, const int *point, const int *dist, int &bPointNr, int &bDistance)
+    {
+        int c[N];
+        W.template icost_points<N>(x, y, c);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            if (take(c[k] + mvcost_fpel(x[k], y[k]), x[k], y[k]))
+            {
+                bPointNr = point[k];
+                bDistance = dist[k];
+            }
+    }
+
+    __device__ void star_pattern(int &bPointNr, int &bDistance, int earlyExit, int merange)
+    {
+        const int ox = bmx, oy = bmy;
+        int saved = bcost, rounds = 0;
+        {
+            const int top = XA_S16(oy - 1), bottom = XA_S16(oy + 1), left = XA_S16(ox - 1), right = XA_S16(ox + 1);
+            if (top >= j.mvmin_y && left >= j.mvmin_x && right <= j.mvmax_x && bottom <= j.mvmax_y)
+            {
+                int x[4] = { ox, left, right, ox }, y[4] = { top, oy, oy, bottom };
+                int p[4] = { 2, 4, 5, 7 }, d[4] = { 1, 1, 1, 1 };
+                pts<4>(x, y, p, d, bPointNr, bDistance);
+            }
+            else
+            {
+                if (top >= j.mvmin_y)    pt(ox, top, 2, 1, bPointNr, bDistance);
+                if (left >= j.mvmin_x)   pt(left, oy, 4, 1, bPointNr, bDistance);
+                if (right <= j.mvmax_x)  pt(right, oy, 5, 1, bPointNr, bDistance);
+                if (bottom <= j.mvmax_y) pt(ox, bottom, 7, 1, bPointNr, bDistance);
+            }
+            if (bcost < saved)
+                rounds = 0;
+            else if (++rounds >= earlyExit)
+                return;
+        }
+        for (int dist = 2; dist <= 8; dist <<= 1)
+        {
+            const int top = XA_S16(oy - dist), bottom = XA_S16(oy + dist), left = XA_S16(ox - dist), right = XA_S16(ox + dist);
+            const int hd = dist >> 1;
+            const int top2 = XA_S16(oy - hd), bottom2 = XA_S16(oy + hd), left2 = XA_S16(ox - hd), right2 = XA_S16(ox + hd);
+            saved = bcost;
+            if (top >= j.mvmin_y && left >= j.mvmin_x && right <= j.mvmax_x && bottom <= j.mvmax_y)
+            {
+                int x[8] = { ox, left2, right2, left, right, left2, right2, ox };
+                int y[8] = { top, top2, top2, oy, oy, bottom2, bottom2, bottom };
+                int p[8] = { 2, 1, 3, 4, 5, 6, 8, 7 };
+                int d[8] = { dist, hd, hd, dist, dist, hd, hd, dist };
+                pts<8>(x, y, p, d, bPointNr, bDistance);
+            }
+            else
+            {
+                if (top >= j.mvmin_y) pt(ox, top, 2, dist, bPointNr, bDistance);
+                if (top2 >= j.mvmin_y)
+                {
+                    if (left2 >= j.mvmin_x)  pt(left2, top2, 1, hd, bPointNr, bDistance);
+                    if (right2 <= j.mvmax_x) pt(right2, top2, 3, hd, bPointNr, bDistance);
+                }
+                if (left >= j.mvmin_x)  pt(left, oy, 4, dist, bPointNr, bDistance);
+                if (right <= j.mvmax_x) pt(right, oy, 5, dist, bPointNr, bDistance);
+                if (bottom2 <= j.mvmax_y)
+                {
+                    if (left2 >= j.mvmin_x)  pt(left2, bottom2, 6, hd, bPointNr, bDistance);
+                    if (right2 <= j.mvmax_x) pt(right2, bottom2, 8, hd, bPointNr, bDistance);
+                }
+                if (bottom <= j.mvmax_y) pt(ox, bottom, 7, dist, bPointNr, bDistance);
+            }
+            if (bcost < saved)
+                rounds = 0;
+            else if (++rounds >= earlyExit)
+                return;
+        }
+        for (int dist = 16; dist <= XA_S16(merange); dist = XA_S16(dist << 1))
+        {
+            const int top = XA_S16(oy - dist), bottom = XA_S16(oy + dist), left = XA_S16(ox - dist), right = XA_S16(ox + dist);
+            const int q = dist >> 2;
+            saved = bcost;
+            if (top >= j.mvmin_y && left >= j.mvmin_x && right <= j.mvmax_x && bottom <= j.mvmax_y)
+            {
+                int zero[4] = { 0, 0, 0, 0 }, dd[4] = { dist, dist, dist, dist };
+                {
+                    int x[4] = { ox, left, right, ox }, y[4] = { top, oy, oy, bottom };
+                    pts<4>(x, y, zero, dd, bPointNr, bDistance);
+                }
+                for (int idx = 1; idx < 4; idx++)
+                {
+                    int yt = XA_S16(top + q * idx), yb = XA_S16(bottom - q * idx);
+                    int xl = XA_S16(ox - q * idx), xr = XA_S16(ox + q * idx);
+                    int x[4] = { xl, xr, xl, xr }, y[4] = { yt, yt, yb, yb };
+                    pts<4>(x, y, zero, dd, bPointNr, bDistance);
+                }
+            }
+            else
+            {
+                if (top >= j.mvmin_y)    pt(ox, top, 0, dist, bPointNr, bDistance);
+                if (left >= j.mvmin_x)   pt(left, oy, 0, dist, bPointNr, bDistance);
+                if (right <= j.mvmax_x)  pt(right, oy, 0, dist, bPointNr, bDistance);
+                if (bottom <= j.mvmax_y) pt(ox, bottom, 0, dist, bPointNr, bDistance);
+                for (int idx = 1; idx < 4; idx++)
+                {
+                    int yt = XA_S16(top + q * idx), yb = XA_S16(bottom - q * idx);
+                    int xl = XA_S16(ox - q * idx), xr = XA_S16(ox + q * idx);
+                    if (yt >= j.mvmin_y)
+                    {
+                        if (xl >= j.mvmin_x) pt(xl, yt, 0, dist, bPointNr, bDistance);
+                        if (xr <= j.mvmax_x) pt(xr, yt, 0, dist, bPointNr, bDistance);
+                    }
+                    if (yb <= j.mvmax_y)
+                    {
+                        if (xl >= j.mvmin_x) pt(xl, yb, 0, dist, bPointNr, bDistance);
+                        if (xr <= j.mvmax_x) pt(xr, yb, 0, dist, bPointNr, bDistance);
+                    }
+                }
+            }
+            if (bcost < saved)
+                rounds = 0;
+            else if (++rounds >= earlyExit)
+                return;
+        }
+    }
+
+    __device__ void star_two_points(int bPointNr)
+    {
+        const int x1 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2][0]), y1 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2][1]);
+        const int x2 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2 + 1][0]), y2 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2 + 1][1]);
+        if (in_range(x1, y1)) try_mv(x1, y1);
+        if (in_range(x2, y2)) try_mv(x2, y2);
+    }
+
+    // ---------------------------------------------------------------- UMH helpers (motion.cpp:443-628)
+    // Quirk kept from the reference: inside the UMH block every x4 evaluation measures its SADs
+    // relative to the search START (pix_base is computed once, motion.cpp:451) while the candidates
+    // are labelled and priced relative to the CURRENT omv.
+    __device__ void umh_x4(int basex, int basey, int omx, int omy,
+                           int a0, int a1, int b0, int b1, int c0, int c1, int d0, int d1)
+    {
+        int sx[4] = { basex + a0, basex + b0, basex + c0, basex + d0 };
+        int sy[4] = { basey + a1, basey + b1, basey + c1, basey + d1 };
+        int lx[4] = { XA_S16(omx + a0), XA_S16(omx + b0), XA_S16(omx + c0), XA_S16(omx + d0) };
+        int ly[4] = { XA_S16(omy + a1), XA_S16(omy + b1), XA_S16(omy + c1), XA_S16(omy + d1) };
+        try_points<4>(sx, sy, lx, ly);
+    }
+
+    // CROSS (motion.cpp:251-275).  Second quirk: COST_MV(omv.x, omv.y + i) expands to
+    // fref + omv.x + omv.y + i * stride, i.e. the vertical singles are measured at
+    // (omv.x + omv.y, +-i) but labelled (omv.x, omv.y +- i).
+    __device__ void umh_cross(int basex, int basey, int omx, int omy, int start, int x_max, int y_max)
+    {
+        int i = XA_S16(start);
+        int lim = j.mvmax_x - omx < omx - j.mvmin_x ? j.mvmax_x - omx : omx - j.mvmin_x;
+        if (x_max <= lim)
+            for (; i < x_max - 2; i = XA_S16(i + 4))
+                umh_x4(basex, basey, omx, omy, i, 0, -i, 0, i + 2, 0, -i - 2, 0);
+        for (; i < x_max; i = XA_S16(i + 2))
+        {
+            if (omx + i <= j.mvmax_x) try_mv(omx + i, omy);
+            if (omx - i >= j.mvmin_x) try_mv(omx - i, omy);
+        }
+        i = XA_S16(start);
+        lim = j.mvmax_y - omy < omy - j.mvmin_y ? j.mvmax_y - omy : omy - j.mvmin_y;
+        if (y_max <= lim)
+            for (; i < y_max - 2; i = XA_S16(i + 4))
+                umh_x4(basex, basey, omx, omy, 0, i, 0, -i, 0, i + 2, 0, -i - 2);
+        for (; i < y_max; i = XA_S16(i + 2))
+        {
+            if (omy + i <= j.mvmax_y)
+            {
+                int sx = omx + omy, sy = i, lx = omx, ly = omy + i;
+                try_points<1>(&sx, &sy, &lx, &ly);
+            }
+            if (omy - i >= j.mvmin_y)
+            {
+                int sx = omx + omy, sy = -i, lx = omx, ly = omy - i;
+                try_points<1>(&sx, &sy, &lx, &ly);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- the search
+    __device__ int run(const FullBest *fb, int &outx, int &outy)
+    {
+        int merange = j.merange;
+        W.ikind = j.icost;
+        W.mvpx = j.qmvp_x;
+        W.mvpy = j.qmvp_y;
+        const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
+        const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);
+        auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };   // MV::clipped, mv.h:88-93
+
+        // predictor phase (motion.cpp:302-342)
+        int pmx = clipq(j.qmvp_x, qminx, qmaxx), pmy = clipq(j.qmvp_y, qminy, qmaxy);
+        int bprex = pmx, bprey = pmy;
+        int bprecost = W.subpel_cost(pmx, pmy, W.ikind);          // no mvcost term (motion.cpp:305)
+        bmx = XA_S16(XA_S16(pmx + 2) >> 2);
+        bmy = XA_S16(XA_S16(pmy + 2) >> 2);
+        bcost = bprecost;
+        if ((pmx | pmy) & 3)
+            bcost = W.cost_fpel(bmx, bmy);
+        if (pmx || pmy)
+        {
+            int zx = 0, zy = 0, c;
+            W.template icost_points<1>(&zx, &zy, &c);
+            c += W.mvcost(0, 0);
+            if (c < bcost)
+            {
+                bcost = c;
+                bmx = bmy = 0;
+            }
+        }
+        for (int i = 0; i < j.numc; i++)
+        {
+            int mx = clipq(j.mvc[i][0], qminx, qmaxx), my = clipq(j.mvc[i][1], qminy, qmaxy);
+            if ((mx || my) && !(mx == pmx && my == pmy) && !(mx == bprex && my == bprey))
+            {
+                int c = W.subpel_cost(mx, my, W.ikind) + W.mvcost(mx, my);
+                if (c < bprecost)
+                {
+                    bprecost = c;
+                    bprex = mx;
+                    bprey = my;
+                }
+            }
+        }
+        pmx = XA_S16(XA_S16(pmx + 2) >> 2);
+        pmy = XA_S16(XA_S16(pmy + 2) >> 2);
+        int omx = bmx, omy = bmy;
+        bool do_hex = false;
+
+        switch (j.method)
+        {
+        case X265AMD_DIA:   // motion.cpp:346-367
+        {
+            int i = merange;
+            do
+            {
+                const int cx = bmx, cy = bmy;
+                int k = probe<4>(cx, cy, &c_square1[1]);
+                if (k < 0)
+                    break;
+                bmx = XA_S16(cx + c_square1[k + 1][0]);
+                bmy = XA_S16(cy + c_square1[k + 1][1]);
+            }
+            while (--i && in_range(bmx, bmy));
+            break;
+        }
+        case X265AMD_HEX:
+            do_hex = true;
+            break;
+
+        case X265AMD_UMH:
+        {
+            const int basex = bmx, basey = bmy;
+            const int scale = (W.w * W.h) >> 4;           // size_scale[] (motion.cpp:64-80)
+            int cross_start = 1;
+#define SAD_THRESH(v) (bcost < (((v) >> 4) * scale))
+            int ucost1 = bcost, ucost2;
+            omx = pmx; omy = pmy;
+            umh_x4(basex, basey, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
+            if (pmx || pmy)
+            {
+                omx = 0; omy = 0;
+                umh_x4(basex, basey, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
+            }
+            ucost2 = bcost;
+            if ((bmx || bmy) && !(bmx == pmx && bmy == pmy))
+            {
+                omx = bmx; omy = bmy;
+                umh_x4(basex, basey, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
+            }
+            if (bcost == ucost2)
+                cross_start = 3;
+            omx = bmx; omy = bmy;
+            bool terminated = false;
+            if (bcost == ucost2 && SAD_THRESH(2000))
+            {
+                umh_x4(basex, basey, omx, omy, 0, -2, -1, -1, 1, -1, -2, 0);
+                umh_x4(basex, basey, omx, omy, 2, 0, -1, 1, 1, 1, 0, 2);
+                if (bcost == ucost1 && SAD_THRESH(500))
+                    terminated = true;
+                else if (bcost == ucost2)
+                {
+                    int range = XA_S16(XA_S16(merange >> 1) | 1);
+                    umh_cross(basex, basey, omx, omy, 3, range, range);
+                    umh_x4(basex, basey, omx, omy, -1, -2, 1, -2, -2, -1, 2, -1);
+                    umh_x4(basex, basey, omx, omy, -2, 1, 2, 1, -1, 2, 1, 2);
+                    if (bcost == ucost2)
+                        terminated = true;
+                    else
+                        cross_start = range + 2;
+                }
+            }
+            if (terminated)
+                break;
+
+            if (j.numc)   // adaptive range from predictor spread (motion.cpp:486-538)
+            {
+                int mvd, denom = 1;
+                const bool is64 = (W.w == 64 && W.h == 64);
+                auto iabs = [](int v) { return v < 0 ? -v : v; };
+                if (j.numc == 1)
+                {
+                    if (is64)
+                        mvd = 25;
+                    else
+                        mvd = iabs(j.qmvp_x - j.mvc[0][0]) + iabs(j.qmvp_y - j.mvc[0][1]);
+                }
+                else
+                {
+                    denom = j.numc - 1;
+                    mvd = 0;
+                    if (!is64)
+                    {
+                        mvd = iabs(j.qmvp_x - j.mvc[0][0]) + iabs(j.qmvp_y - j.mvc[0][1]);
+                        denom++;
+                    }
+                    for (int i = 0; i < j.numc - 1; i++)
+                        mvd += iabs(j.mvc[i][0] - j.mvc[i + 1][0]) + iabs(j.mvc[i][1] - j.mvc[i + 1][1]);
+                }
+                int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+                int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                merange = (merange * c_range_mul[mvd_ctx][sad_ctx]) >> 2;
+            }
+#undef SAD_THRESH
+            umh_cross(basex, basey, omx, omy, cross_start, merange, merange >> 1);
+            umh_x4(basex, basey, omx, omy, -2, -2, -2, 2, 2, -2, 2, 2);
+
+            // hexagon grid (motion.cpp:545-624)
+            omx = bmx; omy = bmy;
+            int i = 1;
+            do
+            {
+                int m1 = j.mvmax_x - omx < omx - j.mvmin_x ? j.mvmax_x - omx : omx - j.mvmin_x;
+                int m2 = j.mvmax_y - omy < omy - j.mvmin_y ? j.mvmax_y - omy : omy - j.mvmin_y;
+                if (4 * i > (m1 < m2 ? m1 : m2))
+                {
+                    for (int k = 0; k < 16; k++)
+                    {
+                        int mx = XA_S16(omx + XA_S16(c_hex4[k][0] * i)), my = XA_S16(omy + XA_S16(c_hex4[k][1] * i));
+                        if (in_range(mx, my))
+                            try_mv(mx, my);
+                    }
+                }
+                else
+                {
+                    // unclipped ring: 4 x sad_x4; mvcost read straight from the table rows at omv*4,
+                    // not truncated to 16 bits (motion.cpp:547-548,575); bmv is set after all 16
+                    int best = -1;
+                    for (int q = 0; q < 4; q++)
+                    {
+                        int x[4], y[4], c[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            x[k] = omx + c_hex4[q * 4 + k][0] * i;
+                            y[k] = omy + c_hex4[q * 4 + k][1] * i;
+                        }
+                        W.template icost_points<4>(x, y, c);
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            int cc = c[k] + W.cost[(int16_t)(omx * 4 + c_hex4[q * 4 + k][0] * 4 * i - W.mvpx)]
+                                          + W.cost[(int16_t)(omy * 4 + c_hex4[q * 4 + k][1] * 4 * i - W.mvpy)];
+                            cc = uni(cc);
+                            if (cc < bcost)
+                            {
+                                bcost = cc;
+                                best = q * 4 + k;
+                            }
+                        }
+                    }
+                    if (best >= 0)
+                    {
+                        bmx = XA_S16(omx + i * c_hex4[best][0]);
+                        bmy = XA_S16(omy + i * c_hex4[best][1]);
+                    }
+                }
+                i = XA_S16(i + 1);
+            }
+            while (i <= (merange >> 2));
+            if (in_range(bmx, bmy))
+                do_hex = true;
+            break;
+        }
+
+        case X265AMD_STAR:  // motion.cpp:630-737
+        {
+            int bPointNr = 0, bDistance = 0;
+            star_pattern(bPointNr, bDistance, 3, merange);
+            bool stop = false;
+            if (bDistance == 1)
+            {
+                if (bPointNr)
+                {
+                    int saved = bcost;
+                    star_two_points(bPointNr);
+                    if (bcost == saved)
+                        stop = true;
+                }
+                else
+                    stop = true;
+            }
+            if (stop)
+                break;
+            if (bDistance > 5)      // raster refinement, step 5 (motion.cpp:667-701)
+            {
+                for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty = XA_S16(ty + 5))
+                    for (int tx = j.mvmin_x; tx <= j.mvmax_x; tx = XA_S16(tx + 5))
+                    {
+                        if (tx + 15 <= j.mvmax_x)
+                        {
+                            int x[4] = { tx, tx + 5, tx + 10, tx + 15 }, y[4] = { ty, ty, ty, ty }, c[4];
+                            W.template icost_points<4>(x, y, c);
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                            {
+                                // quirk: the 4th candidate is priced with mvcost(tmv << 3) (motion.cpp:694)
+                                int sh = (k == 3) ? 3 : 2;
+                                int lx = XA_S16(x[k]);
+                                take(c[k] + W.mvcost(XA_S16(lx << sh), XA_S16(ty << sh)), lx, ty);
+                            }
+                            tx = XA_S16(tx + 15);
+                        }
+                        else
+                            try_mv(tx, ty);
+                    }
+            }
+            while (bDistance > 0)
+            {
+                bDistance = 0;
+                bPointNr = 0;
+                star_pattern(bPointNr, bDistance, 32, merange);
+                if (bDistance == 1)
+                {
+                    if (!bPointNr)
+                        break;
+                    star_two_points(bPointNr);
+                    break;
+                }
+            }
+            break;
+        }
+
+        case X265AMD_FULL:  // motion.cpp:738-771
+        default:
+            if (fb)
+            {
+                // the exhaustive raster scan ran in its own kernel; its winner is the first
+                // minimum in raster order, which is what strict-`<` updates would have kept
+                if (fb->cost < bcost)
+                {
+                    bcost = fb->cost;
+                    bmx = fb->mvx;
+                    bmy = fb->mvy;
+                }
+                int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+                W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;
+            }
+            else
+            {
+                for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty++)
+                {
+                    int tx = j.mvmin_x;
+                    for (; tx + 3 <= j.mvmax_x; tx += 4)
+                    {
+                        int x[4] = { tx, tx + 1, tx + 2, tx + 3 }, y[4] = { ty, ty, ty, ty };
+                        try_points<4>(x, y, x, y);
+                    }
+                    for (; tx <= j.mvmax_x; tx++)
+                        try_mv(tx, ty);
+                }
+            }
+            break;
+        }
+
+        if (do_hex)     // me_hex2 (motion.cpp:369-441)
+        {
+            int dir = probe<6>(bmx, bmy, &c_hex2[1]);
+            if (dir >= 0)
+            {
+                bmx = XA_S16(bmx + c_hex2[dir + 1][0]);
+                bmy = XA_S16(bmy + c_hex2[dir + 1][1]);
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy); i--)
+                {
+                    int step = probe<3>(bmx, bmy, &c_hex2[dir]);
+                    if (step < 0)
+                        break;
+                    dir = (dir + step - 1 + 6) % 6;
+                    bmx = XA_S16(bmx + c_hex2[dir + 1][0]);
+                    bmy = XA_S16(bmy + c_hex2[dir + 1][1]);
+                }
+            }
+            int sq = probe<8>(bmx, bmy, &c_square1[1]);
+            bmx = XA_S16(bmx + c_square1[sq + 1][0]);
+            bmy = XA_S16(bmy + c_square1[sq + 1][1]);
+        }
+
+        // motion.cpp:778-784
+        if (bprecost < bcost)
+        {
+            bmx = bprex;
+            bmy = bprey;
+            bcost = bprecost;
+        }
+        else
+        {
+            bmx = XA_S16(bmx << 2);
+            bmy = XA_S16(bmy << 2);
+        }
+
+        // sub-pel refinement (motion.cpp:786-861).  The reference's half-pel loop interpolates one
+        // (w+1)xh or wx(h+1) block per direction pair; both members share the fractional phase,
+        // so each candidate equals an independent subpelCompare.
+        const int8_t *wl = c_workload[j.subme];
+        const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
+        if (wl[4])
+            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD) + W.mvcost(bmx, bmy);
+        for (int it = 0; it < wl[0]; it++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[1]; i++)
+            {
+                int qx = XA_S16(bmx + c_square1[i][0] * 2), qy = XA_S16(bmy + c_square1[i][1] * 2);
+                int c = W.subpel_cost(qx, qy, hkind) + W.mvcost(qx, qy);
+                if (c < bcost)
+                {
+                    bcost = c;
+                    bdir = i;
+                }
+            }
+            bmx = XA_S16(bmx + c_square1[bdir][0] * 2);
+            bmy = XA_S16(bmy + c_square1[bdir][1] * 2);
+        }
+        if (!wl[4])
+            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD) + W.mvcost(bmx, bmy);
+        for (int it = 0; it < wl[2]; it++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[3]; i++)
+            {
+                int qx = XA_S16(bmx + c_square1[i][0]), qy = XA_S16(bmy + c_square1[i][1]);
+                int c = W.subpel_cost(qx, qy, X265AMD_SATD) + W.mvcost(qx, qy);
+                if (c < bcost)
+                {
+                    bcost = c;
+                    bdir = i;
+                }
+            }
+            bmx = XA_S16(bmx + c_square1[bdir][0]);
+            bmy = XA_S16(bmy + c_square1[bdir][1]);
+        }
+        outx = bmx;
+        outy = bmy;
+        return bcost;
+    }
+};
+
+} // namespace xa

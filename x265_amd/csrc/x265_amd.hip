@@ -1,0 +1,683 @@
+// x265_amd C ABI (include/x265_amd.h): context, planes, MV cost tables and kernel launches.
+// Everything computes on the GPU; there is no host fallback.
+#include "me_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace xa;
+
+namespace {
+
+// lambda^2 for non-I slices per QP (reference: Lib/TLibCommon/TComRom.cpp:527-536)
+const double k_lambda2_non_I[52] =
+{
+    0.05231, 0.060686, 0.07646, 0.096333333, 0.151715667, 0.15292, 0.192666667, 0.242745, 0.382299,
+    0.385333333, 0.485489333, 0.611678333, 0.963333333, 0.970979, 1.223356667, 1.541333333, 2.427447667,
+    2.446714, 3.082666667, 3.883916667, 6.116785, 6.165333333, 7.767833333, 9.786856667, 15.41333333,
+    16.57137733, 22.183542, 29.5936, 39.357022, 52.19656867, 69.05173333, 91.14257667, 150.0651347,
+    157.8325333, 207.1422197, 271.4221573, 443.904, 447.4271947, 563.722941, 710.2464, 1118.567987,
+    1127.445883, 1420.4928, 1789.70878, 2818.614706, 2840.9856, 3579.41756, 4509.78353, 7102.464,
+    7158.83512, 9019.56706, 11363.9424
+};
+
+const int k_dims[8] = { 4, 8, 12, 16, 24, 32, 48, 64 };
+
+struct DevBuf
+{
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct x265amd_ctx
+{
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    std::mutex   mu;
+    std::string  err = "";
+
+    PlaneDesc    h_planes[MAX_PLANES];
+    bool         used[MAX_PLANES];
+    void        *owned[MAX_PLANES];       // device allocation owned by the context (upload) or NULL (wrapped)
+    void        *base[MAX_PLANES];        // device address of the padded allocation
+    PlaneDesc   *d_planes = nullptr;
+    bool         planes_dirty = true;
+
+    std::vector<float>    bitsizes;       // BitCost::s_bitsizes
+    std::vector<uint16_t> h_cost[52];
+    uint16_t    *d_cost = nullptr;        // 52 x 65536
+    unsigned long long *d_evals = nullptr;
+
+    DevBuf jobs, results, fullbest, pairs, costs, stage;
+    void  *h_stage = nullptr;             // pinned staging for the per-call primitives
+    size_t h_stage_cap = 0;
+    int    max_lds = 0;
+};
+
+namespace {
+
+int fail(x265amd_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    if (c)
+        c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), X265AMD_ERR_HIP, #call, e_); } while (0)
+
+int ensure(x265amd_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes)
+        return 0;
+    if (b.p)
+    {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return 0;
+}
+
+// BitCost::CalculateLogs + BitCost::setQP (reference: encoder/bitcost.cpp:35-85).  The float /
+// double expression shapes are kept (this file is compiled with -ffp-contract=off).
+void build_cost_tables(x265amd_ctx *c)
+{
+    c->bitsizes.resize(32769);
+    c->bitsizes[0] = 0.718f;
+    float log2_2 = 2.0f / logf(2.0f);
+    for (int i = 1; i <= 32768; i++)
+        c->bitsizes[i] = logf((float)(i + 1)) * log2_2 + 1.718f;
+    for (int qp = 0; qp < 52; qp++)
+    {
+        std::vector<uint16_t> &t = c->h_cost[qp];
+        t.assign(65536, 0);
+        double lambda = sqrt(k_lambda2_non_I[qp]);
+        for (int i = 0; i < 32768; i++)
+        {
+            double v = c->bitsizes[i] * lambda + 0.5f;
+            uint16_t e = (uint16_t)(v < 65535 ? v : 65535);
+            t[32768 + i] = e;
+            t[32768 - i] = e;
+        }
+    }
+}
+
+int sync_planes(x265amd_ctx *c)
+{
+    if (!c->planes_dirty)
+        return 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(c->h_planes), hipMemcpyHostToDevice, c->stream));
+    // h_planes may change right after this call returns
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->planes_dirty = false;
+    return 0;
+}
+
+int add_plane(x265amd_ctx *c, void *dev_base, void *owned, int width, int height, int margin_x, int margin_y,
+              intptr_t stride, int bpp, int depth, int *plane_id)
+{
+    int id = -1;
+    for (int i = 0; i < MAX_PLANES; i++)
+        if (!c->used[i])
+        {
+            id = i;
+            break;
+        }
+    if (id < 0)
+        return fail(c, X265AMD_ERR_NOMEM, "too many planes registered");
+    PlaneDesc &d = c->h_planes[id];
+    int64_t org = (int64_t)margin_y * stride + margin_x;
+    d.origin = (const char*)dev_base + org * bpp;
+    d.lo = -org;
+    d.hi = (int64_t)(height + 2 * margin_y) * stride - org;
+    d.stride = (int32_t)stride;
+    d.width = width;
+    d.height = height;
+    d.bpp = bpp;
+    d.depth = depth;
+    d.margin_x = margin_x;
+    d.margin_y = margin_y;
+    c->used[id] = true;
+    c->owned[id] = owned;
+    c->base[id] = dev_base;
+    c->planes_dirty = true;
+    *plane_id = id;
+    return 0;
+}
+
+int check_plane_args(x265amd_ctx *c, int width, int height, int margin_x, int margin_y, intptr_t stride, int bpp, int depth)
+{
+    if (width <= 0 || height <= 0 || margin_x < 0 || margin_y < 0 || stride < width + 2 * margin_x ||
+        (bpp != 1 && bpp != 2) || depth < 8 || depth > 8 * bpp || depth > 14)
+        return fail(c, X265AMD_ERR_INVALID, "bad plane geometry");
+    return 0;
+}
+
+bool valid_dim(int v)
+{
+    for (int i = 0; i < 8; i++)
+        if (k_dims[i] == v)
+            return true;
+    return false;
+}
+
+BatchParams make_params(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs)
+{
+    BatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.planes = c->d_planes;
+    for (int q = 0; q < 52; q++)
+        P.cost[q] = c->d_cost + (size_t)q * 65536 + 32768;
+    P.enc_plane = enc_plane;
+    P.n_refs = n_refs;
+    for (int i = 0; i < n_refs; i++)
+        P.ref_planes[i] = ref_planes[i];
+    return P;
+}
+
+int check_batch_planes(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs)
+{
+    if (enc_plane < 0 || enc_plane >= MAX_PLANES || !c->used[enc_plane])
+        return fail(c, X265AMD_ERR_INVALID, "enc_plane is not a registered plane");
+    if (n_refs < 1 || n_refs > X265AMD_MAX_REFS || !ref_planes)
+        return fail(c, X265AMD_ERR_INVALID, "bad reference plane list");
+    for (int i = 0; i < n_refs; i++)
+    {
+        int r = ref_planes[i];
+        if (r < 0 || r >= MAX_PLANES || !c->used[r])
+            return fail(c, X265AMD_ERR_INVALID, "ref plane is not a registered plane");
+        if (c->h_planes[r].bpp != c->h_planes[enc_plane].bpp)
+            return fail(c, X265AMD_ERR_INVALID, "enc and ref planes differ in pixel size");
+    }
+    return 0;
+}
+
+// launch the exhaustive kernel (if the batch can contain eligible jobs) and the general kernel
+int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
+                  x265amd_me_result *d_out, bool maybe_full, int lds_bytes)
+{
+    FullBest *fb = nullptr;
+    if (maybe_full && bpp == 1)
+    {
+        if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest)))
+            return rc;
+        fb = (FullBest*)c->fullbest.p;
+        hipLaunchKernelGGL(k_full_u8, dim3(n), dim3(256), lds_bytes, c->stream, P, d_jobs, n, fb, lds_bytes / 4);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (bpp == 1)
+        hipLaunchKernelGGL(k_search<uint8_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
+    else
+        hipLaunchKernelGGL(k_search<uint16_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+constexpr int FULL_LDS_DEFAULT = 64 * 1024;
+
+} // namespace
+
+extern "C" {
+
+int x265amd_partition_from_sizes(int w, int h)
+{
+    int wi = -1, hi = -1;
+    for (int i = 0; i < 8; i++)
+    {
+        if (k_dims[i] == w) wi = i;
+        if (k_dims[i] == h) hi = i;
+    }
+    return (wi < 0 || hi < 0) ? -1 : (wi << 3) + hi;
+}
+
+int x265amd_create(int device, x265amd_ctx **out)
+{
+    if (!out)
+        return X265AMD_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return X265AMD_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess)
+        return X265AMD_ERR_NO_DEVICE;
+    x265amd_ctx *c = new x265amd_ctx;
+    c->device = device;
+    memset(c->h_planes, 0, sizeof(c->h_planes));
+    memset(c->used, 0, sizeof(c->used));
+    memset(c->owned, 0, sizeof(c->owned));
+    memset(c->base, 0, sizeof(c->base));
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->d_planes, sizeof(c->h_planes))) != hipSuccess ||
+        (e = hipMalloc(&c->d_cost, (size_t)52 * 65536 * sizeof(uint16_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_evals, sizeof(unsigned long long))) != hipSuccess)
+    {
+        fprintf(stderr, "x265amd_create: %s\n", hipGetErrorString(e));
+        delete c;
+        return X265AMD_ERR_HIP;
+    }
+    build_cost_tables(c);
+    for (int q = 0; q < 52; q++)
+        if ((e = hipMemcpy(c->d_cost + (size_t)q * 65536, c->h_cost[q].data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess)
+        {
+            delete c;
+            return X265AMD_ERR_HIP;
+        }
+    hipMemset(c->d_evals, 0, sizeof(unsigned long long));
+    // the exhaustive kernel uses up to 64 KiB of dynamic LDS
+    e = hipFuncSetAttribute((const void*)k_full_u8, hipFuncAttributeMaxDynamicSharedMemorySize, FULL_LDS_DEFAULT);
+    if (e != hipSuccess)
+    {
+        fprintf(stderr, "x265amd_create: kernels not loadable on this device: %s\n", hipGetErrorString(e));
+        delete c;
+        return X265AMD_ERR_NO_DEVICE;
+    }
+    c->max_lds = FULL_LDS_DEFAULT;
+    *out = c;
+    return X265AMD_OK;
+}
+
+void x265amd_destroy(x265amd_ctx *c)
+{
+    if (!c)
+        return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < MAX_PLANES; i++)
+        if (c->used[i] && c->owned[i])
+            hipFree(c->owned[i]);
+    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage };
+    for (DevBuf *b : bufs)
+        if (b->p)
+            hipFree(b->p);
+    if (c->h_stage)
+        hipHostFree(c->h_stage);
+    hipFree(c->d_planes);
+    hipFree(c->d_cost);
+    hipFree(c->d_evals);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *x265amd_last_error(const x265amd_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int x265amd_sync(x265amd_ctx *c)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void *x265amd_stream(x265amd_ctx *c) { return c ? (void*)c->stream : nullptr; }
+
+int x265amd_plane_upload(x265amd_ctx *c, const void *host_base, int width, int height, int margin_x, int margin_y,
+                         intptr_t stride, int bpp, int depth, int *plane_id)
+{
+    if (!c || !host_base || !plane_id)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_plane_args(c, width, height, margin_x, margin_y, stride, bpp, depth))
+        return rc;
+    size_t bytes = (size_t)(height + 2 * margin_y) * stride * bpp;
+    void *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, bytes + 64));     // slack so that clamped dword reads at the very end stay inside
+    hipError_t e = hipMemcpyAsync(d, host_base, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+    {
+        hipFree(d);
+        return fail(c, X265AMD_ERR_HIP, "plane upload", e);
+    }
+    int rc = add_plane(c, d, d, width, height, margin_x, margin_y, stride, bpp, depth, plane_id);
+    if (rc)
+        hipFree(d);
+    return rc;
+}
+
+int x265amd_plane_wrap_device(x265amd_ctx *c, void *dev_base, int width, int height, int margin_x, int margin_y,
+                              intptr_t stride, int bpp, int depth, int *plane_id)
+{
+    if (!c || !dev_base || !plane_id)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (int rc = check_plane_args(c, width, height, margin_x, margin_y, stride, bpp, depth))
+        return rc;
+    return add_plane(c, dev_base, nullptr, width, height, margin_x, margin_y, stride, bpp, depth, plane_id);
+}
+
+void *x265amd_plane_device_ptr(x265amd_ctx *c, int id)
+{
+    if (!c || id < 0 || id >= MAX_PLANES || !c->used[id])
+        return nullptr;
+    return c->base[id];
+}
+
+int x265amd_plane_release(x265amd_ctx *c, int id)
+{
+    if (!c || id < 0 || id >= MAX_PLANES || !c->used[id])
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->owned[id])
+        hipFree(c->owned[id]);
+    c->used[id] = false;
+    c->owned[id] = nullptr;
+    c->base[id] = nullptr;
+    memset(&c->h_planes[id], 0, sizeof(PlaneDesc));
+    c->planes_dirty = true;
+    return 0;
+}
+
+int x265amd_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x265amd_block_pair *pairs, int32_t *out)
+{
+    if (!c || !pairs || !out || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (kind < X265AMD_SAD || kind > X265AMD_SA8D || !valid_dim(w) || !valid_dim(h))
+        return fail(c, X265AMD_ERR_INVALID, "bad cost kind or block size");
+    int bpp = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_block_pair &p = pairs[i];
+        if (p.enc_plane < 0 || p.enc_plane >= MAX_PLANES || !c->used[p.enc_plane] ||
+            p.ref_plane < 0 || p.ref_plane >= MAX_PLANES || !c->used[p.ref_plane])
+            return fail(c, X265AMD_ERR_INVALID, "block pair names an unregistered plane");
+        const PlaneDesc &e = c->h_planes[p.enc_plane], &r = c->h_planes[p.ref_plane];
+        if (e.bpp != r.bpp || (bpp && e.bpp != bpp))
+            return fail(c, X265AMD_ERR_INVALID, "mixed pixel sizes in one cost batch");
+        bpp = e.bpp;
+        // blocks must lie inside the padded planes
+        if (p.enc_x < -e.margin_x || p.enc_y < -e.margin_y || p.enc_x + w > e.width + e.margin_x || p.enc_y + h > e.height + e.margin_y ||
+            p.ref_x < -r.margin_x || p.ref_y < -r.margin_y || p.ref_x + w > r.width + r.margin_x || p.ref_y + h > r.height + r.margin_y)
+            return fail(c, X265AMD_ERR_RANGE, "block outside the padded plane");
+    }
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->pairs, (size_t)n * sizeof(x265amd_block_pair))) return rc;
+    if (int rc = ensure(c, c->costs, (size_t)n * sizeof(int32_t))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, pairs, (size_t)n * sizeof(x265amd_block_pair), hipMemcpyHostToDevice, c->stream));
+    if (bpp == 1)
+        hipLaunchKernelGGL(k_cost<uint8_t>, dim3(n), dim3(64), 0, c->stream, c->d_planes, kind, w, h,
+                           (const x265amd_block_pair*)c->pairs.p, n, (int32_t*)c->costs.p);
+    else
+        hipLaunchKernelGGL(k_cost<uint16_t>, dim3(n), dim3(64), 0, c->stream, c->d_planes, kind, w, h,
+                           (const x265amd_block_pair*)c->pairs.p, n, (int32_t*)c->costs.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->costs.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int validate_jobs(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, bool *any_full)
+{
+    *any_full = false;
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_me_job &j = jobs[i];
+        if (!valid_dim(j.w) || !valid_dim(j.h))
+            return fail(c, X265AMD_ERR_INVALID, "job size is not a partition size");
+        if (j.method > X265AMD_FULL || j.subme > 7 || j.qp > 51 || j.numc > X265AMD_MAX_MVC ||
+            j.ref_idx >= n_refs || j.icost > X265AMD_SA8D || j.merange < 0)
+            return fail(c, X265AMD_ERR_INVALID, "job field out of range");
+        if (j.method == X265AMD_UMH && j.w == 4 && j.h == 4)
+            return fail(c, X265AMD_ERR_INVALID, "UMH does not support 4x4 (the reference asserts, encoder/motion.cpp:447)");
+        if (j.method == X265AMD_FULL)
+            *any_full = true;
+    }
+    return 0;
+}
+
+int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
+                            const x265amd_me_job *jobs, int n, x265amd_me_result *out)
+{
+    if (!c || !jobs || !out || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    bool any_full = false;
+    if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->jobs, (size_t)n * sizeof(x265amd_me_job))) return rc;
+    if (int rc = ensure(c, c->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
+    BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
+    if (int rc = launch_search(c, P, c->h_planes[enc_plane].bpp, (const x265amd_me_job*)c->jobs.p, n,
+                               (x265amd_me_result*)c->results.p, any_full, c->max_lds))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->results.p, (size_t)n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
+                                   const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out)
+{
+    if (!c || !d_jobs || !d_out || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = sync_planes(c)) return rc;
+    BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
+    return launch_search(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out, true, c->max_lds);
+}
+
+int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    HIPCHK(c, hipMemcpy(&v, c->d_evals, sizeof(v), hipMemcpyDeviceToHost));
+    if (evals)
+        *evals = v;
+    if (reset)
+        HIPCHK(c, hipMemset(c->d_evals, 0, sizeof(v)));
+    return 0;
+}
+
+int x265amd_mvcost_table(x265amd_ctx *c, int qp, uint16_t *out)
+{
+    if (!c || !out || qp < 0 || qp > 51)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    // read back what the kernels actually use
+    HIPCHK(c, hipMemcpy(out, c->d_cost + (size_t)qp * 65536, 65536 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// BitCost::bitcost (reference: encoder/bitcost.h:49-53)
+int x265amd_bitcost(x265amd_ctx *c, int mvp_x, int mvp_y, int mv_x, int mv_y)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    int ax = abs(mv_x - mvp_x), ay = abs(mv_y - mvp_y);
+    if (ax > 16383 || ay > 16383)
+        return X265AMD_ERR_INVALID;
+    return (uint16_t)(c->bitsizes[(ax << 1) + !!(mv_x < mvp_x)] + c->bitsizes[(ay << 1) + !!(mv_y < mvp_y)] + 0.5f);
+}
+
+} // extern "C"
+
+// -------------------------------------------------------------------------------------------
+// Per-call primitives with the reference's signatures (common/primitives.h:180-184).
+// A process-wide context per pixel size; each call packs its blocks (any caller stride, e.g. the
+// TestBench's odd 59) into pinned staging, copies them to the device as small stride-w planes
+// and runs k_cost on one pair per reference pointer.
+
+namespace {
+
+struct PrimCtx
+{
+    x265amd_ctx *ctx = nullptr;
+    std::mutex   mu;
+    int          bpp = 0;
+};
+PrimCtx g_prim[3];
+
+// copy `rows` rows of `row_elems` pixels with stride `stride` into pinned staging at byte offset `at`
+size_t stage_block(x265amd_ctx *c, size_t at, const void *src, intptr_t stride, int row_elems, int rows, int bpp)
+{
+    char *dst = (char*)c->h_stage + at;
+    for (int y = 0; y < rows; y++)
+        memcpy(dst + (size_t)y * row_elems * bpp, (const char*)src + (intptr_t)y * stride * bpp, (size_t)row_elems * bpp);
+    return at + (size_t)rows * row_elems * bpp;
+}
+
+// fenc (stride fs) against nref blocks (stride rs); results to res[0..nref)
+int prim_eval(int bpp, int kind, int w, int h, const void *fenc, intptr_t fs, const void *const *fref, int nref, intptr_t rs, int *res)
+{
+    PrimCtx &pc = g_prim[bpp];
+    if (!pc.ctx)
+    {
+        fprintf(stderr, "x265_amd: primitive called before x265amd_setup_primitives()\n");
+        abort();
+    }
+    std::lock_guard<std::mutex> g(pc.mu);
+    x265amd_ctx *c = pc.ctx;
+    hipSetDevice(c->device);
+    // staged layout: [fenc w x h][ref0 w x h]...; each becomes a margin-less plane of stride w
+    size_t blk = (size_t)w * h * bpp;
+    size_t need = blk * (1 + nref) + 64;
+    if (c->h_stage_cap < need)
+    {
+        if (c->h_stage) hipHostFree(c->h_stage);
+        c->h_stage_cap = need < (1 << 16) ? (1 << 16) : need;
+        if (hipHostMalloc(&c->h_stage, c->h_stage_cap) != hipSuccess) { fprintf(stderr, "x265_amd: pinned alloc failed\n"); abort(); }
+    }
+    if (ensure(c, c->stage, c->h_stage_cap)) { fprintf(stderr, "x265_amd: %s\n", c->err.c_str()); abort(); }
+    size_t at = stage_block(c, 0, fenc, fs, w, h, bpp);
+    for (int k = 0; k < nref; k++)
+        at = stage_block(c, at, fref[k], rs, w, h, bpp);
+    hipMemcpyAsync(c->stage.p, c->h_stage, at, hipMemcpyHostToDevice, c->stream);
+    // temporary planes: slots at the top of the table; the valid range of each is the whole staging buffer
+    int ids[5];
+    x265amd_block_pair pairs[4];
+    {
+        std::lock_guard<std::mutex> g2(c->mu);
+        for (int k = 0; k <= nref; k++)
+        {
+            int id = MAX_PLANES - 1 - k;
+            ids[k] = id;
+            PlaneDesc &d = c->h_planes[id];
+            int64_t first = (int64_t)((blk * k) / bpp);
+            d.origin = (const char*)c->stage.p + blk * k;
+            d.lo = -first;
+            d.hi = (int64_t)(c->stage.cap / bpp) - first;
+            d.stride = w;
+            d.width = w;
+            d.height = h;
+            d.bpp = bpp;
+            d.depth = bpp == 1 ? 8 : 10;
+            d.margin_x = d.margin_y = 0;
+            c->used[id] = true;
+            c->owned[id] = nullptr;
+        }
+        c->planes_dirty = true;
+        if (sync_planes(c)) { fprintf(stderr, "x265_amd: %s\n", c->err.c_str()); abort(); }
+    }
+    for (int k = 0; k < nref; k++)
+        pairs[k] = x265amd_block_pair{ ids[0], 0, 0, ids[k + 1], 0, 0 };
+    int32_t out[4];
+    int rc = x265amd_cost_batch(c, kind, w, h, nref, pairs, out);
+    if (rc) { fprintf(stderr, "x265_amd: primitive failed: %s\n", x265amd_last_error(c)); abort(); }
+    for (int k = 0; k < nref; k++)
+        res[k] = out[k];
+    return 0;
+}
+
+template <int BPP, int KIND, int PART>
+int prim_cmp(void *fenc, intptr_t fs, void *fref, intptr_t rs)
+{
+    int r;
+    const void *refs[1] = { fref };
+    prim_eval(BPP, KIND, k_dims[PART >> 3], k_dims[PART & 7], fenc, fs, refs, 1, rs, &r);
+    return r;
+}
+template <int BPP, int PART>
+void prim_x3(void *fenc, void *r0, void *r1, void *r2, intptr_t rs, int *res)
+{
+    const void *refs[3] = { r0, r1, r2 };
+    prim_eval(BPP, X265AMD_SAD, k_dims[PART >> 3], k_dims[PART & 7], fenc, X265AMD_FENC_STRIDE, refs, 3, rs, res);
+}
+template <int BPP, int PART>
+void prim_x4(void *fenc, void *r0, void *r1, void *r2, void *r3, intptr_t rs, int *res)
+{
+    const void *refs[4] = { r0, r1, r2, r3 };
+    prim_eval(BPP, X265AMD_SAD, k_dims[PART >> 3], k_dims[PART & 7], fenc, X265AMD_FENC_STRIDE, refs, 4, rs, res);
+}
+
+template <int BPP, int PART>
+struct Fill
+{
+    static void run(x265amd_primitives *p)
+    {
+        p->sad[PART] = prim_cmp<BPP, X265AMD_SAD, PART>;
+        p->satd[PART] = prim_cmp<BPP, X265AMD_SATD, PART>;
+        p->sa8d_inter[PART] = prim_cmp<BPP, X265AMD_SA8D, PART>;
+        p->sad_x3[PART] = prim_x3<BPP, PART>;
+        p->sad_x4[PART] = prim_x4<BPP, PART>;
+        Fill<BPP, PART - 1>::run(p);
+    }
+};
+template <int BPP>
+struct Fill<BPP, -1> { static void run(x265amd_primitives*) {} };
+
+} // namespace
+
+extern "C" int x265amd_setup_primitives(x265amd_primitives *p, int device, int bytes_per_px)
+{
+    if (!p || (bytes_per_px != 1 && bytes_per_px != 2))
+        return X265AMD_ERR_INVALID;
+    PrimCtx &pc = g_prim[bytes_per_px];
+    {
+        std::lock_guard<std::mutex> g(pc.mu);
+        if (!pc.ctx)
+        {
+            int rc = x265amd_create(device, &pc.ctx);
+            if (rc)
+                return rc;
+            pc.bpp = bytes_per_px;
+        }
+    }
+    if (bytes_per_px == 1)
+        Fill<1, 63>::run(p);
+    else
+        Fill<2, 63>::run(p);
+    // sa8d[] for square intra blocks equals sa8d_inter of the square partition
+    // (reference: common/pixel.cpp:750-754 vs :756-826)
+    for (int i = 0; i < 5; i++)
+        p->sa8d[i] = p->sa8d_inter[x265amd_partition_from_sizes(4 << i, 4 << i)];
+    return X265AMD_OK;
+}
