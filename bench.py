@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Motion-estimation benchmark (one JSON line on rank 0).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step = one whole-frame ME pass of the hot path on every rank:
+  * rank 0 owns the reconstructed reference plane; with N > 1 it is broadcast to the other
+    ranks over RCCL (the path's only exchange step), then
+  * every rank searches ITS OWN current 1080p frame (frame rank+1 of the synthetic sequence)
+    against that reference -- frames are independent, so the work is sharded with no other
+    collective (weak scaling: one frame per GPU per step).
+
+Workload of `value` (BASELINE.json configs[1]): 1920x1080 8-bit, HEX search, merange 64, +-64
+window rule of the encoder, subme 5 (8 half-pel + 8 quarter-pel SATD), PUs 16x16 and 64x64.
+The same run also measures configs[0] on the GPU (FULL +-64 SAD, PUs 64/32/16/8) and reports it
+under "full_search", with the SAD-ALU roofline the exhaustive kernel is bound by.
+
+Planes, job lists and result buffers are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from x265_amd import jobs as J  # noqa: E402
+from x265_amd import synth  # noqa: E402
+
+W, H = 1920, 1080
+QP = 32
+MERANGE = 64
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+SAD_LANES_PER_CLK_PER_CU = 64  # v_sad_u8 issue rate measured with tools/ubench_sad (lane-ops/clk/CU)
+
+
+def build_job_lists():
+    hex_jobs = J.frame_jobs(W, H, sizes=(64, 16), method=J.HEX, subme=5, merange=MERANGE, qp=QP)
+    full_jobs = J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=MERANGE, qp=QP)
+    return hex_jobs, full_jobs
+
+
+def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=10.0):
+    """Time the CPU path on the host cores for a bounded sample of the same workloads.
+    kind 'reference' = the reference's own C path (oracle/_ref, compiled from the reference's
+    sources), 1 thread; falls back to kind 'port' (oracle/libme_oracle.so) if it is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as F
+    oracle = F.Oracle()
+    out = {}
+
+    def time_ref(jobs):
+        lib = F.Reference(8)
+        mv = np.zeros((len(jobs), 2), dtype=np.int16)
+        cost = np.zeros(len(jobs), dtype=np.int32)
+        jb = np.ascontiguousarray(jobs)
+        lib.lib.ref_me_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        t0 = time.perf_counter()
+        lib.lib.ref_me_search_batch(lib.me, F.plane_origin(enc), enc.shape[1], F.plane_origin(ref), ref.shape[1],
+                                    jb.ctypes.data, len(jb), mv.ctypes.data, cost.ctypes.data)
+        dt = time.perf_counter() - t0
+        res = np.zeros(len(jobs), dtype=J.RESULT_DTYPE)
+        res["mvx"], res["mvy"], res["cost"] = mv[:, 0], mv[:, 1], cost
+        return dt, res
+
+    def time_port(jobs, threads):
+        t0 = time.perf_counter()
+        res, evals = oracle.search(enc, [ref], jobs, threads=threads)
+        return time.perf_counter() - t0, res, evals
+
+    kind = "reference" if F.have_reference(8) else "port"
+    # HEX workload: the whole frame's job list is ~0.2 s of CPU work; repeat a fixed sample
+    hs = hex_jobs[::2]
+    _, _, hex_evals = time_port(hs[:64], 1)
+    reps, dt = 0, 0.0
+    while dt < budget_s * 0.5 and reps < 200:
+        d, res = time_ref(hs) if kind == "reference" else time_port(hs, 1)[:2]
+        dt += d
+        reps += 1
+    _, chk, hex_evals = time_port(hs, 8)
+    assert np.array_equal(chk, res), "CPU baseline legs disagree"
+    out["hex"] = {"value": hex_evals * reps / dt, "unit": "evals/s", "cores": 1, "kind": kind,
+                  "sample": "%d of %d jobs of the HEX+subme5 frame (every 2nd), %d repetitions, %.1f s" % (len(hs), len(hex_jobs), reps, dt)}
+    # FULL workload: ~0.15 s per 64x64 PU on one core -> a strided sample of PUs of all four sizes
+    fs = np.concatenate([full_jobs[full_jobs["w"] == s][:: st] for s, st in ((64, 24), (32, 50), (16, 100), (8, 200))])
+    d, res = time_ref(fs) if kind == "reference" else time_port(fs, 1)[:2]
+    fe = J.full_search_evals(fs)
+    px = float((J.full_search_evals(fs[fs["w"] == 64]) * 4096 + J.full_search_evals(fs[fs["w"] == 32]) * 1024 +
+                J.full_search_evals(fs[fs["w"] == 16]) * 256 + J.full_search_evals(fs[fs["w"] == 8]) * 64))
+    out["full"] = {"value": fe / d, "unit": "evals/s", "pixel_sads_per_s": px / d, "cores": 1, "kind": kind,
+                   "sample": "%d PUs (strided over 64/32/16/8) of the FULL+-64 frame, %.1f s" % (len(fs), d)}
+    # all host cores given to this job, on the port (one search state per thread)
+    cores = min(16, os.cpu_count() or 1)
+    d, _, ev = time_port(hs, cores)
+    out["hex_mt"] = {"value": ev / d, "unit": "evals/s", "cores": cores, "kind": "port"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--full-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from x265_amd.api import Engine
+    eng = Engine(local_rank)
+
+    # ---- inputs, resident in HBM ---------------------------------------------------------
+    base = synth.base_frame(W, H)
+    ref_np = synth.pad_plane(base)                                  # frame 0 = reference (owned by rank 0)
+    enc_np = synth.pad_plane(synth.moved_frame(base, rank + 1))     # this rank's current frame
+    stride = ref_np.shape[1]
+    enc_t = torch.from_numpy(enc_np).to(dev)
+    ref_t = torch.from_numpy(ref_np).to(dev) if rank == 0 else torch.zeros(ref_np.shape, dtype=torch.uint8, device=dev)
+    enc_id = eng.wrap_device_plane(enc_t.data_ptr(), W, H, stride, 1, 8)
+    ref_id = eng.wrap_device_plane(ref_t.data_ptr(), W, H, stride, 1, 8)
+
+    hex_jobs, full_jobs = build_job_lists()
+    d_hex = torch.from_numpy(hex_jobs.view(np.uint8).reshape(-1)).to(dev)
+    d_full = torch.from_numpy(full_jobs.view(np.uint8).reshape(-1)).to(dev)
+    d_hex_out = torch.zeros(len(hex_jobs) * 8, dtype=torch.uint8, device=dev)
+    d_full_out = torch.zeros(len(full_jobs) * 8, dtype=torch.uint8, device=dev)
+    eng.set_timing(True)
+
+    def step(d_jobs, n, d_out):
+        if world > 1:
+            dist.broadcast(ref_t, src=0)          # reference plane: rank 0 -> all, RCCL over xGMI
+            torch.cuda.current_stream().synchronize()   # the search runs on the engine's own stream
+        eng.search_device(enc_id, [ref_id], d_jobs.data_ptr(), n, d_out.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(d_jobs, n, d_out, warmup, steps):
+        for _ in range(warmup):
+            step(d_jobs, n, d_out)
+        eng.sync()
+        eng.eval_count(reset=True)
+        barrier()
+        kt = [0.0, 0.0]
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(d_jobs, n, d_out)
+            a, b = eng.kernel_times()             # waits for the batch: steps do not overlap
+            kt[0] += a
+            kt[1] += b
+        barrier()
+        dt = time.perf_counter() - t0
+        evals = eng.eval_count()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            e = torch.tensor([evals], dtype=torch.float64, device=dev)
+            dist.all_reduce(e, op=dist.ReduceOp.SUM)
+            evals = float(e.item())
+        return dt, evals, kt[0] / steps, kt[1] / steps
+
+    # ---- primary: HEX + subme 5 ------------------------------------------------------------
+    dt, evals, _, k_search_ms = timed(d_hex, len(hex_jobs), d_hex_out, args.warmup, args.steps)
+    hex_res = d_hex_out.cpu().numpy().view(J.RESULT_DTYPE)
+    value = evals / dt
+    ms_per_step = dt / args.steps * 1e3
+    # algorithmic HBM bytes of one launch: enc plane + ref plane read once, jobs read, results written
+    alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
+    achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
+
+    # ---- secondary: FULL +-64 (configs[0] on the GPU) --------------------------------------
+    fdt, fevals, k_full_ms, k_tail_ms = timed(d_full, len(full_jobs), d_full_out, 1, args.full_steps)
+    full_res = d_full_out.cpu().numpy().view(J.RESULT_DTYPE)
+    prop = torch.cuda.get_device_properties(local_rank)
+    cus = prop.multi_processor_count
+    clk_hz = prop.clock_rate * 1e3 if hasattr(prop, "clock_rate") else 2.4e9
+    px_per_frame = float(sum(J.full_search_evals(full_jobs[full_jobs["w"] == s]) * s * s for s in (64, 32, 16, 8)))
+    sad_peak = cus * SAD_LANES_PER_CLK_PER_CU * 4 * clk_hz
+    full_px_rate = px_per_frame / (k_full_ms * 1e-3)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("k_search_u8_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "ME block-cost evals/sec",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "frames_per_s": world * args.steps / dt,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 hpel + 8 qpel SATD), PUs 16x16+64x64 "
+                               "(BASELINE configs[1]); one frame per GPU per step; reference plane broadcast from rank 0",
+                   "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": evals / (args.steps * world),
+                   "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "full_search": {"workload": "1080p 8-bit, FULL +-64 SAD, PUs 64/32/16/8, subme 0 (BASELINE configs[0] on the GPU)",
+                        "value": fevals / fdt, "unit": "evals/s", "frames_per_s": world * args.full_steps / fdt,
+                        "ms_per_frame": fdt / args.full_steps * 1e3, "jobs_per_frame": int(len(full_jobs)),
+                        "roofline": {"bound": "valu", "kernel": "k_full_u8", "achieved": full_px_rate / 1e12, "peak": sad_peak / 1e12,
+                                     "unit": "T pixel-SAD/s", "frac": full_px_rate / sad_peak, "kernel_ms": k_full_ms,
+                                     "search_kernel_ms": k_tail_ms,
+                                     "peak_def": "%d CUs x %d lanes/clk x 4 px (v_sad_u8) x %.2f GHz" % (cus, SAD_LANES_PER_CLK_PER_CU, clk_hz / 1e9)}},
+    }
+
+    if not args.no_cpu:
+        cb = cpu_baseline(enc_np, ref_np, hex_jobs, full_jobs)
+        line["cpu_baseline"] = cb["hex"]
+        line["cpu_baseline_full_search"] = cb["full"]
+        line["cpu_baseline_all_cores"] = cb["hex_mt"]
+        # the GPU and CPU legs ran the same jobs: their results must agree (checker, not product)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_ffi as F
+        o = F.Oracle()
+        chk, _ = o.search(enc_np, [ref_np], hex_jobs[::5], threads=8)
+        line["parity_sample_ok"] = bool(np.array_equal(chk, hex_res[::5]))
+        fsel = np.arange(0, len(full_jobs), 400)
+        chk, _ = o.search(enc_np, [ref_np], full_jobs[fsel], threads=8)
+        line["parity_sample_ok"] = line["parity_sample_ok"] and bool(np.array_equal(chk, full_res[fsel]))
+
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,14 @@ int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *r
  * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */
 int x265amd_eval_count(x265amd_ctx *ctx, int reset, uint64_t *evals);
 
+/* Kernel timing: when enabled, every search batch brackets its kernels with HIP events on the
+ * context's stream, the way the reference brackets its two motionEstimate calls with
+ * CYCLE_COUNTER_START/STOP(ME) (Lib/TLibEncoder/TEncSearch.cpp:2424-2451, common/common.h:110-125).
+ * x265amd_kernel_times returns, for the most recent batch, ms[0] = exhaustive (FULL) kernel,
+ * ms[1] = general search kernel (0 if a kernel did not run); it waits for the batch. */
+int x265amd_set_timing(x265amd_ctx *ctx, int enable);
+int x265amd_kernel_times(x265amd_ctx *ctx, float ms[2]);
+
 /* MV-cost model (encoder/bitcost.h:43-53, encoder/bitcost.cpp:35-85) */
 /* out[i + 32768] = BitCost::s_costs[qp][i], i in [-32767, 32767]; out[0] = 0 */
 int x265amd_mvcost_table(x265amd_ctx *ctx, int qp, uint16_t *out65536);

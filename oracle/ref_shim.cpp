@@ -190,6 +190,27 @@ int ref_me_search(void *h,
     return cost;
 }
 
+/* The same over an array of jobs laid out like meo_job (oracle/me_oracle.h, 48 bytes each),
+ * all against one reference plane: used to time the reference's CPU path without per-job FFI cost. */
+struct ShimJob
+{
+    int32_t pu_x, pu_y;
+    int16_t w, h, mvmin[2], mvmax[2], qmvp[2], merange;
+    uint8_t method, subme, qp, numc, ref_idx, icost;
+    int16_t mvc[4][2];
+};
+
+void ref_me_search_batch(void *h, pixel *enc, intptr_t encStride, pixel *ref, intptr_t refStride,
+                         const void *jobs, int n, int16_t *out_mv, int *out_cost)
+{
+    const ShimJob *j = (const ShimJob*)jobs;
+    for (int i = 0; i < n; i++)
+        out_cost[i] = ref_me_search(h, enc, encStride, ref, refStride, NULL,
+                                    (int)(j[i].pu_y * encStride + j[i].pu_x), j[i].w, j[i].h,
+                                    j[i].mvmin, j[i].mvmax, j[i].qmvp, j[i].numc, &j[i].mvc[0][0],
+                                    j[i].merange, j[i].method, j[i].subme, j[i].qp, out_mv + 2 * i);
+}
+
 /* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */
 int ref_me_buf(void *h, int kind, pixel *enc, intptr_t encStride, int puOffset, int w, int hgt,
                pixel *fref, intptr_t stride)

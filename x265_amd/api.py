@@ -67,6 +67,8 @@ def load_library() -> C.CDLL:
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
+    L.x265amd_set_timing.argtypes = [vp, ci]
+    L.x265amd_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.x265amd_mvcost_table.argtypes = [vp, ci, vp]
     L.x265amd_bitcost.argtypes = [vp, ci, ci, ci, ci]
     L.x265amd_setup_primitives.argtypes = [C.POINTER(Primitives), ci, ci]
@@ -155,6 +157,15 @@ class Engine:
         v = C.c_uint64(0)
         self._chk(self.lib.x265amd_eval_count(self.h, int(reset), C.byref(v)))
         return v.value
+
+    def set_timing(self, enable: bool = True):
+        self._chk(self.lib.x265amd_set_timing(self.h, int(enable)))
+
+    def kernel_times(self):
+        """(ms of the exhaustive kernel, ms of the general search kernel) of the last batch"""
+        ms = (C.c_float * 2)()
+        self._chk(self.lib.x265amd_kernel_times(self.h, ms))
+        return float(ms[0]), float(ms[1])
 
     def mvcost_table(self, qp: int) -> np.ndarray:
         out = np.zeros(65536, dtype=np.uint16)

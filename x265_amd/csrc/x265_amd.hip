@@ -60,6 +60,9 @@ struct x265amd_ctx
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
     int    max_lds = 0;
+    bool   timing = false;
+    bool   timed_full = false, timed_any = false;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 };
 
 namespace {
@@ -214,6 +217,14 @@ int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_m
                   x265amd_me_result *d_out, bool maybe_full, int lds_bytes)
 {
     FullBest *fb = nullptr;
+    if (c->timing)
+    {
+        for (int i = 0; i < 3; i++)
+            if (!c->ev[i])
+                HIPCHK(c, hipEventCreate(&c->ev[i]));
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    }
+    c->timed_full = false;
     if (maybe_full && bpp == 1)
     {
         if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest)))
@@ -221,12 +232,20 @@ int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_m
         fb = (FullBest*)c->fullbest.p;
         hipLaunchKernelGGL(k_full_u8, dim3(n), dim3(256), lds_bytes, c->stream, P, d_jobs, n, fb, lds_bytes / 4);
         HIPCHK(c, hipGetLastError());
+        c->timed_full = true;
     }
+    if (c->timing)
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (bpp == 1)
         hipLaunchKernelGGL(k_search<uint8_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
     else
         hipLaunchKernelGGL(k_search<uint16_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
     HIPCHK(c, hipGetLastError());
+    if (c->timing)
+    {
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        c->timed_any = true;
+    }
     return 0;
 }
 
@@ -309,6 +328,9 @@ void x265amd_destroy(x265amd_ctx *c)
             hipFree(b->p);
     if (c->h_stage)
         hipHostFree(c->h_stage);
+    for (int i = 0; i < 3; i++)
+        if (c->ev[i])
+            hipEventDestroy(c->ev[i]);
     hipFree(c->d_planes);
     hipFree(c->d_cost);
     hipFree(c->d_evals);
@@ -503,6 +525,32 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
         *evals = v;
     if (reset)
         HIPCHK(c, hipMemset(c->d_evals, 0, sizeof(v)));
+    return 0;
+}
+
+int x265amd_set_timing(x265amd_ctx *c, int enable)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->timing = enable != 0;
+    c->timed_any = false;
+    return 0;
+}
+
+int x265amd_kernel_times(x265amd_ctx *c, float ms[2])
+{
+    if (!c || !ms)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    ms[0] = ms[1] = 0.f;
+    if (!c->timing || !c->timed_any)
+        return fail(c, X265AMD_ERR_INVALID, "no timed batch (call x265amd_set_timing first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev[2]));
+    if (c->timed_full)
+        HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));
     return 0;
 }
 
