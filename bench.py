@@ -142,17 +142,16 @@ def main():
     ref_id = eng.wrap_device_plane(ref_t.data_ptr(), W, H, stride, 1, 8)
 
     hex_jobs, full_jobs = build_job_lists()
-    d_hex = torch.from_numpy(hex_jobs.view(np.uint8).reshape(-1)).to(dev)
-    d_full = torch.from_numpy(full_jobs.view(np.uint8).reshape(-1)).to(dev)
-    d_hex_out = torch.zeros(len(hex_jobs) * 8, dtype=torch.uint8, device=dev)
-    d_full_out = torch.zeros(len(full_jobs) * 8, dtype=torch.uint8, device=dev)
+    # planned job lists: jobs, work-item plan and result buffers live in device memory
+    jl_hex = eng.make_joblist(hex_jobs)
+    jl_full = eng.make_joblist(full_jobs)
     eng.set_timing(True)
 
-    def step(d_jobs, n, d_out):
+    def step(jl):
         if world > 1:
             dist.broadcast(ref_t, src=0)          # reference plane: rank 0 -> all, RCCL over xGMI
             torch.cuda.current_stream().synchronize()   # the search runs on the engine's own stream
-        eng.search_device(enc_id, [ref_id], d_jobs.data_ptr(), n, d_out.data_ptr())
+        jl.run(enc_id, [ref_id], fetch=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,16 +159,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(d_jobs, n, d_out, warmup, steps):
+    def timed(jl, warmup, steps):
         for _ in range(warmup):
-            step(d_jobs, n, d_out)
+            step(jl)
         eng.sync()
         eng.eval_count(reset=True)
         barrier()
         kt = [0.0, 0.0]
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(d_jobs, n, d_out)
+            step(jl)
             a, b = eng.kernel_times()             # waits for the batch: steps do not overlap
             kt[0] += a
             kt[1] += b
@@ -186,8 +185,8 @@ def main():
         return dt, evals, kt[0] / steps, kt[1] / steps
 
     # ---- primary: HEX + subme 5 ------------------------------------------------------------
-    dt, evals, _, k_search_ms = timed(d_hex, len(hex_jobs), d_hex_out, args.warmup, args.steps)
-    hex_res = d_hex_out.cpu().numpy().view(J.RESULT_DTYPE)
+    dt, evals, _, k_search_ms = timed(jl_hex, args.warmup, args.steps)
+    hex_res = jl_hex.run(enc_id, [ref_id], fetch=True)
     value = evals / dt
     ms_per_step = dt / args.steps * 1e3
     # algorithmic HBM bytes of one launch: enc plane + ref plane read once, jobs read, results written
@@ -195,8 +194,8 @@ def main():
     achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
 
     # ---- secondary: FULL +-64 (configs[0] on the GPU) --------------------------------------
-    fdt, fevals, k_full_ms, k_tail_ms = timed(d_full, len(full_jobs), d_full_out, 1, args.full_steps)
-    full_res = d_full_out.cpu().numpy().view(J.RESULT_DTYPE)
+    fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, 1, args.full_steps)
+    full_res = jl_full.run(enc_id, [ref_id], fetch=True)
     prop = torch.cuda.get_device_properties(local_rank)
     cus = prop.multi_processor_count
     clk_hz = prop.clock_rate * 1e3 if hasattr(prop, "clock_rate") else 2.4e9

@@ -130,6 +130,20 @@ int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_plan
 int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                                    const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
 
+/* Planned job lists.  An encoder searches the same PU geometry frame after frame; a job list
+ * keeps the jobs in device memory and plans the exhaustive kernel once (PUs of one size that
+ * share a 32x32 cell share one staged search window; large PUs are cut into candidate-row slabs).
+ * Results are identical to x265amd_me_search_batch on the same jobs.  The reference analogue is
+ * the per-slice set-up before the per-PU calls (Lib/TLibEncoder/TEncSearch.cpp:2332-2364). */
+typedef struct x265amd_joblist x265amd_joblist;
+int x265amd_joblist_create(x265amd_ctx *ctx, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,
+                           x265amd_joblist **out);
+/* run the list against planes; out == NULL: asynchronous, results stay in device memory */
+int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
+                        x265amd_me_result *out);
+const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
+int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
+
 /* number of block-cost evaluations executed by the search kernels since the counter was last
  * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */
 int x265amd_eval_count(x265amd_ctx *ctx, int reset, uint64_t *evals);

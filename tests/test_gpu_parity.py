@@ -196,6 +196,41 @@ def test_full_search_properties_at_full_size(eng, oracle):
         eng.release_plane(i)
 
 
+def test_device_resident_and_planned_paths_agree(eng, oracle):
+    """The three ways in (host batch, raw device job array, planned job list) give identical,
+    oracle-exact results; the job list mixes FULL jobs of every size class with pattern searches."""
+    import torch
+    W, H = 416, 240
+    fr = synth.make_sequence(W, H, 3, seed=321)
+    ids = [eng.upload_plane(f) for f in fr]
+    rng = np.random.default_rng(8)
+    parts = [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=2, merange=40, qp=30, qmvp=(5, -9)),
+             J.frame_jobs(W, H, sizes=(16,), method=J.FULL, subme=0, merange=64, qp=22),
+             J.frame_jobs(W, H, sizes=(32, 8), method=J.HEX, subme=5, merange=32, qp=37, ref_idx=1)]
+    for (w, h) in ((4, 4), (8, 4), (12, 16), (24, 32), (48, 64), (64, 16), (16, 64), (4, 16)):
+        x, y = J.square_pu_grid(W, H, max(w, h))
+        parts.append(J.make_jobs(W, H, x[::2], y[::2], w, h, method=J.FULL, subme=1, merange=int(rng.integers(3, 30)),
+                                 qp=28, qmvp=(int(rng.integers(-40, 40)), int(rng.integers(-40, 40))), ref_idx=int(rng.integers(0, 2))))
+    jobs = np.concatenate(parts)
+    exp, _ = oracle.search(fr[0], [fr[1], fr[2]], jobs, threads=8)
+    a = eng.search(ids[0], [ids[1], ids[2]], jobs)
+    assert np.array_equal(a, exp), np.nonzero(a != exp)[0][:5]
+    jl = eng.make_joblist(jobs, n_refs=2)
+    b = jl.run(ids[0], [ids[1], ids[2]])
+    b2 = jl.run(ids[0], [ids[1], ids[2]])          # a plan is reusable
+    jl.close()
+    assert np.array_equal(b, exp) and np.array_equal(b2, exp)
+    dev = torch.device("cuda", 0)
+    dj = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
+    do = torch.zeros(len(jobs) * 8, dtype=torch.uint8, device=dev)
+    eng.search_device(ids[0], [ids[1], ids[2]], dj.data_ptr(), len(jobs), do.data_ptr())
+    eng.sync()
+    c = do.cpu().numpy().view(J.RESULT_DTYPE)
+    assert np.array_equal(c, exp), np.nonzero(c != exp)[0][:5]
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_errors_are_reported(eng):
     fr = synth.make_sequence(64, 64, 2, seed=1)
     ids = [eng.upload_plane(f) for f in fr]

@@ -41,6 +41,9 @@ __global__ void __launch_bounds__(256) k_valu(u32 *out, u32 seed)
             if (OP == 7) a[k] = __builtin_amdgcn_msad_u8(a[k], b, a[k]);
             if (OP == 8) q[k] = __builtin_amdgcn_mqsad_pk_u16_u8(r64, b, q[k]);
             if (OP == 9) a[k] = __builtin_amdgcn_sad_hi_u8(a[k], b, a[k]);
+            if (OP == 10) q[0] = __builtin_amdgcn_qsad_pk_u16_u8(r64, b, q[0]);          // one dependent chain
+            if (OP == 11) q[k & 1] = __builtin_amdgcn_qsad_pk_u16_u8(r64, b, q[k & 1]);  // two chains
+            if (OP == 12) a[0] = __builtin_amdgcn_sad_u8(a[0], b, a[0]);                  // dependent v_sad_u8 chain
         }
     }
     u32 s = 0;
@@ -119,8 +122,8 @@ int main()
     int blocks = cus * waves_per_cu / 4;
     u32 *out;
     CHECK(hipMalloc(&out, blocks * 256 * 4));
-    const char *names[] = {"v_sad_u8", "v_sad_u16", "v_qsad_pk_u16_u8", "v_mqsad_u32_u8", "v_alignbyte_b32", "v_perm_b32", "v_add_u32", "v_msad_u8", "v_mqsad_pk_u16_u8", "v_sad_hi_u8"};
-    float ms[10];
+    const char *names[] = {"v_sad_u8", "v_sad_u16", "v_qsad_pk_u16_u8", "v_mqsad_u32_u8", "v_alignbyte_b32", "v_perm_b32", "v_add_u32", "v_msad_u8", "v_mqsad_pk_u16_u8", "v_sad_hi_u8", "qsad 1 chain", "qsad 2 chains", "sad_u8 1 chain"};
+    float ms[13];
     ms[0] = time_kernel([&] { k_valu<0><<<blocks, 256>>>(out, 3); });
     ms[1] = time_kernel([&] { k_valu<1><<<blocks, 256>>>(out, 3); });
     ms[2] = time_kernel([&] { k_valu<2><<<blocks, 256>>>(out, 3); });
@@ -131,7 +134,10 @@ int main()
     ms[7] = time_kernel([&] { k_valu<7><<<blocks, 256>>>(out, 3); });
     ms[8] = time_kernel([&] { k_valu<8><<<blocks, 256>>>(out, 3); });
     ms[9] = time_kernel([&] { k_valu<9><<<blocks, 256>>>(out, 3); });
-    for (int i = 0; i < 10; i++)
+    ms[10] = time_kernel([&] { k_valu<10><<<blocks, 256>>>(out, 3); });
+    ms[11] = time_kernel([&] { k_valu<11><<<blocks, 256>>>(out, 3); });
+    ms[12] = time_kernel([&] { k_valu<12><<<blocks, 256>>>(out, 3); });
+    for (int i = 0; i < 13; i++)
     {
         double laneops = (double)blocks * 256 * ITERS * UNROLL;
         double per_clk_cu = laneops / (ms[i] * 1e-3) / clk / cus;

@@ -47,6 +47,13 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise X265AmdError("%s is missing: build it with `python -m x265_amd.build` "
                            "(the HIP kernels are the only compute path)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime.  A process must hold exactly one: when torch is
+    # installed, load it first so that this library binds to the runtime torch uses (device
+    # memory and streams are then shared with torch tensors).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ci, cip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
     L.x265amd_create.argtypes = [ci, C.POINTER(vp)]
@@ -66,6 +73,11 @@ def load_library() -> C.CDLL:
     L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
+    L.x265amd_joblist_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(vp)]
+    L.x265amd_joblist_run.argtypes = [vp, vp, ci, cip, ci, vp]
+    L.x265amd_joblist_results_device.argtypes = [vp]
+    L.x265amd_joblist_results_device.restype = vp
+    L.x265amd_joblist_destroy.argtypes = [vp, vp]
     L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
     L.x265amd_set_timing.argtypes = [vp, ci]
     L.x265amd_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -153,6 +165,9 @@ class Engine:
         refs = (C.c_int * len(ref_planes))(*ref_planes)
         self._chk(self.lib.x265amd_me_search_batch_device(self.h, enc_plane, refs, len(ref_planes), d_jobs_ptr, n, d_out_ptr))
 
+    def make_joblist(self, jobs: np.ndarray, n_refs: int = 1, bytes_per_px: int = 1) -> "JobList":
+        return JobList(self, jobs, n_refs, bytes_per_px)
+
     def eval_count(self, reset: bool = False) -> int:
         v = C.c_uint64(0)
         self._chk(self.lib.x265amd_eval_count(self.h, int(reset), C.byref(v)))
@@ -174,6 +189,35 @@ class Engine:
 
     def bitcost(self, mvp, mv) -> int:
         return self.lib.x265amd_bitcost(self.h, mvp[0], mvp[1], mv[0], mv[1])
+
+
+class JobList:
+    """x265amd_joblist: jobs resident in device memory + the exhaustive kernel's work-item plan."""
+
+    def __init__(self, eng: Engine, jobs: np.ndarray, n_refs: int, bytes_per_px: int):
+        self.eng = eng
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        self.n = len(jobs)
+        h = C.c_void_p()
+        eng._chk(eng.lib.x265amd_joblist_create(eng.h, jobs.ctypes.data, self.n, n_refs, bytes_per_px, C.byref(h)))
+        self.h = h
+
+    def run(self, enc_plane: int, ref_planes, fetch: bool = True):
+        """fetch=True: blocks and returns the results; False: asynchronous, results stay on the device"""
+        refs = (C.c_int * len(ref_planes))(*ref_planes)
+        out = np.zeros(self.n, dtype=RESULT_DTYPE) if fetch else None
+        self.eng._chk(self.eng.lib.x265amd_joblist_run(self.eng.h, self.h, enc_plane, refs, len(ref_planes),
+                                                       out.ctypes.data if fetch else None))
+        return out
+
+    @property
+    def results_device_ptr(self) -> int:
+        return self.eng.lib.x265amd_joblist_results_device(self.h)
+
+    def close(self):
+        if self.h and self.eng.h:
+            self.eng.lib.x265amd_joblist_destroy(self.eng.h, self.h)
+        self.h = None
 
 
 def setup_primitives(device: int = 0, bytes_per_px: int = 1) -> Primitives:

@@ -1,0 +1,364 @@
+// Exhaustive (FULL_SEARCH) integer stage for 8-bit planes, driven by WORK ITEMS.
+//
+// A work item is a set of jobs whose search windows overlap (PUs of one size inside one cell of
+// the picture) plus a range of candidate rows.  One 256-thread workgroup executes one item:
+//   1. the union of the jobs' reference windows is staged into LDS once (row-coalesced dword reads);
+//   2. small PUs (>= 4 jobs in the item): every wavefront takes whole jobs ("wave mode");
+//      large PUs: all four wavefronts split the candidates of one job ("block mode"); a large
+//      job is cut into several items by candidate rows (slabs) so that the machine stays full;
+//   3. a lane task = 4 horizontally consecutive candidates x 2 consecutive candidate rows.  Per
+//      window row the lane holds W4+1 consecutive dwords and issues v_qsad_pk_u16_u8 (4
+//      byte-shifted 4-pixel SADs per instruction -- no byte realignment) against the matching
+//      encoder-block dword, read as an LDS broadcast.  Every window dword feeds both candidate
+//      rows; the next row's operands are loaded while the current row's SADs issue;
+//   4. packed 16-bit partial sums are flushed to 32 bits every <= 256 pixels (cannot overflow);
+//   5. winner = min over (cost << 32 | raster index): the candidate that the reference's
+//      strict-`<` raster scan keeps (reference: encoder/motion.cpp:738-771).
+// The window pitch P is chosen with 2*P == (tasks per row pair) mod 32 so that the 32 lanes of a
+// half-wave always read 32 different LDS banks.
+#pragma once
+
+#include "me_search.h"
+
+namespace xa {
+
+constexpr int FULL_THREADS = 256;
+constexpr int FULL_WAVES = FULL_THREADS / 64;
+constexpr int FB_STRIDE_PLAN = 8;         // FullBest slots per job in a planned job list (max slabs)
+
+struct FullItem
+{
+    int32_t first;        // index of the item's first entry in the item-job index array
+    int32_t count;        // jobs in the item (all of one size and one reference plane)
+    int32_t y_lo, y_hi;   // candidate-row range [y_lo, y_hi) relative to each job's mvmin_y
+    int32_t slot;         // FullBest slot (slab number) the results go to
+    int32_t win_x0, win_y0;   // picture coordinates of the staged window's first pixel
+    int32_t win_rows;     // rows that must be staged for [y_lo, y_hi) (0: derive per tile)
+    int32_t win_nd;       // dwords staged per row
+    int32_t pitch;        // LDS row pitch in dwords
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        unsigned long long o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long lds_pair(const uint32_t *p)
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);        // two consecutive dwords, 4-byte aligned (ds_read2_b32)
+    return v;
+}
+
+// Scan the candidates [y_lo, y_hi) x [0, nx) of one job.  `win` addresses the LDS dword of
+// candidate (0, y_lo) pixel (0,0); tasks are dealt to (id, id + stride, ...).
+// Window row r feeds candidate row A (= y0) with encoder row r and candidate row B (= y0+1) with
+// encoder row r-1.  The 64-bit qsad operand for byte offset 4k is read from LDS as the dword pair
+// (k, k+1) directly: every window dword is fetched twice, but no register shuffling is needed.
+template <int W4>
+__device__ __forceinline__ unsigned long long scan_job(const uint32_t *win, int P, const uint32_t *fenc,
+                                                       const uint16_t *cx, const uint16_t *cy,
+                                                       int h, int nx, int y_lo, int y_hi, int id, int stride)
+{
+    const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1);
+    const int npairs = (y_hi - y_lo + 1) >> 1;
+    const int ntasks = npairs * XGe;
+    const int rows_per_flush = 256 / (4 * W4);
+    unsigned long long best = ~0ull;
+
+    for (int task = id; task < ntasks; task += stride)
+    {
+        const int yp = task / XGe, xg = task - yp * XGe;
+        if (xg >= XG)
+            continue;
+        const uint32_t *row = win + (2 * yp) * P + xg;
+        unsigned long long pa = 0, pb = 0;
+        uint32_t sa[4] = { 0, 0, 0, 0 }, sb[4] = { 0, 0, 0, 0 };
+        uint32_t fA[W4], fB[W4];
+        unsigned long long d[W4];
+        int since = 0;
+
+#define XA_LOAD_WIN(R)  do { _Pragma("unroll") for (int k = 0; k < W4; k++) d[k] = lds_pair(row + (R) * P + k); } while (0)
+#define XA_LOAD_ENC(F, R) do { _Pragma("unroll") for (int k = 0; k < W4; k++) F[k] = fenc[(R) * W4 + k]; } while (0)
+#define XA_QSAD(ACC, F) do { _Pragma("unroll") for (int k = 0; k < W4; k++) ACC = __builtin_amdgcn_qsad_pk_u16_u8(d[k], F[k], ACC); } while (0)
+#define XA_FLUSH()                                                     \
+        do {                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {            \
+                sa[i] += (uint32_t)(pa >> (16 * i)) & 0xffff;          \
+                sb[i] += (uint32_t)(pb >> (16 * i)) & 0xffff; }        \
+            pa = pb = 0; since = 0;                                    \
+        } while (0)
+
+        // rows are taken two at a time so that the encoder rows ping-pong between fA and fB
+        XA_LOAD_WIN(0);
+        XA_LOAD_ENC(fA, 0);
+        XA_QSAD(pa, fA);
+        since = 1;
+        for (int r = 1; r + 1 < h; r += 2)       // h is a multiple of 4: ends with r == h - 1 left over
+        {
+            XA_LOAD_WIN(r);
+            XA_LOAD_ENC(fB, r);
+            XA_QSAD(pb, fA);
+            XA_QSAD(pa, fB);
+            if (++since >= rows_per_flush) XA_FLUSH();
+            XA_LOAD_WIN(r + 1);
+            XA_LOAD_ENC(fA, r + 1);
+            XA_QSAD(pb, fB);
+            XA_QSAD(pa, fA);
+            if (++since >= rows_per_flush) XA_FLUSH();
+        }
+        XA_LOAD_WIN(h - 1);
+        XA_LOAD_ENC(fB, h - 1);
+        XA_QSAD(pb, fA);
+        XA_QSAD(pa, fB);
+        if (++since >= rows_per_flush) XA_FLUSH();
+        XA_LOAD_WIN(h);
+        XA_QSAD(pb, fB);
+        XA_FLUSH();
+#undef XA_LOAD_WIN
+#undef XA_LOAD_ENC
+#undef XA_QSAD
+#undef XA_FLUSH
+
+        const int iy = y_lo + 2 * yp;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+        {
+            const int y = iy + rr;
+            if (y < y_hi)
+            {
+                const int cyv = cy[y];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int x = 4 * xg + i;
+                    if (x < nx)
+                    {
+                        uint32_t c = (rr ? sb[i] : sa[i]) + (uint32_t)((cx[x] + cyv) & 0xffff);
+                        unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(y * nx + x);
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ void write_best(FullBest *out, unsigned long long best, const x265amd_me_job &j, int nx)
+{
+    FullBest f;
+    if (best == ~0ull)
+    {
+        f.cost = 0x7fffffff;
+        f.mvx = f.mvy = 0;
+    }
+    else
+    {
+        int idx = (int)(best & 0xffffffffu);
+        f.cost = (int)(best >> 32);
+        f.mvx = (int16_t)(j.mvmin_x + idx % nx);
+        f.mvy = (int16_t)(j.mvmin_y + idx / nx);
+    }
+    *out = f;
+}
+
+// stage one job's encoder block and MV-cost slices into `scratch` (layout: fenc[h*W4] | cx[nx] | cy[ny] as u16)
+template <int W4>
+__device__ __forceinline__ void stage_job(const PlaneDesc &enc, const uint16_t *cost, const x265amd_me_job &j,
+                                          uint32_t *scratch, int nx, int ny, int id, int stride)
+{
+    const int h = j.h;
+    const uint8_t *e = (const uint8_t*)enc.origin + (int64_t)j.pu_y * enc.stride + j.pu_x;
+    for (int i = id; i < h * W4; i += stride)
+        scratch[i] = ld_u32(e + (int64_t)(i / W4) * enc.stride + 4 * (i % W4));
+    uint16_t *cx = (uint16_t*)(scratch + h * W4), *cy = cx + nx;
+    for (int i = id; i < nx; i += stride)
+        cx[i] = cost[(int16_t)((int16_t)((j.mvmin_x + i) << 2) - j.qmvp_x)];
+    for (int i = id; i < ny; i += stride)
+        cy[i] = cost[(int16_t)((int16_t)((j.mvmin_y + i) << 2) - j.qmvp_y)];
+}
+
+template <int W4>
+__device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs, const int *item_jobs,
+                               const FullItem &it, FullBest *fb, int fb_stride, uint32_t *lds, int lds_dwords)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const PlaneDesc &enc = P.planes[P.enc_plane];
+    const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
+    const PlaneDesc &ref = P.planes[P.ref_planes[j0.ref_idx]];
+    const int h = j0.h;
+    const int pitch = it.pitch, ND = it.win_nd;
+    const bool wave_mode = it.count >= FULL_WAVES;
+
+    // scratch: per wave (wave mode) or one for the block
+    const int scratch_dw = h * W4 + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
+    const int n_scratch = wave_mode ? FULL_WAVES : 1;
+    uint32_t *s_scratch = lds;
+    uint32_t *s_win = lds + n_scratch * scratch_dw;
+    const int rows_fit = (lds_dwords - n_scratch * scratch_dw) / pitch;
+    int TH = (rows_fit - h) & ~1;                 // candidate rows per tile
+    if (TH < 2)
+        return;                                   // cannot happen for planned items
+    const uint8_t *r0 = (const uint8_t*)ref.origin;
+    const int64_t lo = ref.lo, hi = ref.hi - 4;
+
+    unsigned long long blk_best = ~0ull;          // block mode accumulates over tiles
+    for (int ty0 = it.y_lo; ty0 < it.y_hi; ty0 += TH)
+    {
+        const int ty1 = (it.y_hi - ty0 < TH) ? it.y_hi : ty0 + TH;
+        const int rows = it.win_rows ? it.win_rows : (ty1 - ty0) + h - 1 + ((ty1 - ty0) & 1);
+        __syncthreads();
+        for (int r = wv; r < rows; r += FULL_WAVES)
+        {
+            int64_t o = (int64_t)(it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo) + r) * ref.stride + it.win_x0;
+            for (int c = lane; c < ND; c += 64)
+            {
+                int64_t a = o + 4 * c;
+                a = a < lo ? lo : (a > hi ? hi : a);
+                s_win[r * pitch + c] = ld_u32(r0 + a);
+            }
+        }
+        __syncthreads();
+
+        if (wave_mode)
+        {
+            uint32_t *scr = s_scratch + wv * scratch_dw;
+            for (int m = wv; m < it.count; m += FULL_WAVES)
+            {
+                const int jid = item_jobs[it.first + m];
+                const x265amd_me_job &j = jobs[jid];
+                const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+                stage_job<W4>(enc, P.cost[j.qp], j, scr, nx, ny, lane, 64);
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                const int y_hi = ty1 < ny ? ty1 : ny;
+                const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
+                const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
+                const uint16_t *cx = (const uint16_t*)(scr + h * W4);
+                unsigned long long b = scan_job<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64);
+                b = wave_min_u64(b);
+                // a planned wave-mode item covers all candidate rows in one tile
+                if (lane == 0)
+                    write_best(fb + (size_t)jid * fb_stride + it.slot, b, j, nx);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        else
+        {
+            for (int m = 0; m < it.count; m++)
+            {
+                const int jid = item_jobs[it.first + m];
+                const x265amd_me_job &j = jobs[jid];
+                const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+                __syncthreads();
+                stage_job<W4>(enc, P.cost[j.qp], j, s_scratch, nx, ny, tid, FULL_THREADS);
+                __syncthreads();
+                const int y_hi = ty1 < ny ? ty1 : ny;
+                const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
+                const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
+                const uint16_t *cx = (const uint16_t*)(s_scratch + h * W4);
+                unsigned long long b = scan_job<W4>(s_win + wy * pitch + wx, pitch, s_scratch, cx, cx + nx, h, nx, ty0, y_hi, tid, FULL_THREADS);
+                b = wave_min_u64(b);
+                if (it.count == 1)
+                    blk_best = b < blk_best ? b : blk_best;      // reduce across waves after the last tile
+                else
+                {
+                    // several block-mode jobs share the item (always a single tile): reduce now
+                    __syncthreads();
+                    unsigned long long *red = (unsigned long long*)s_scratch;
+                    if (lane == 0) red[wv] = b;
+                    __syncthreads();
+                    if (tid == 0)
+                    {
+                        for (int i = 1; i < FULL_WAVES; i++) b = red[i] < b ? red[i] : b;
+                        write_best(fb + (size_t)jid * fb_stride + it.slot, b, j, nx);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_mode && it.count == 1)
+    {
+        const int jid = item_jobs[it.first];
+        const x265amd_me_job &j = jobs[jid];
+        __syncthreads();
+        unsigned long long *red = (unsigned long long*)s_scratch;
+        if (lane == 0) red[wv] = blk_best;
+        __syncthreads();
+        if (tid == 0)
+        {
+            unsigned long long b = red[0];
+            for (int i = 1; i < FULL_WAVES; i++) b = red[i] < b ? red[i] : b;
+            write_best(fb + (size_t)jid * fb_stride + it.slot, b, j, j.mvmax_x - j.mvmin_x + 1);
+        }
+    }
+}
+
+// One instantiation per PU width so that narrow PUs keep a small register footprint (occupancy).
+// W4 = 0 selects by the item's job width at run time (unplanned path).
+template <int W4>
+__global__ void __launch_bounds__(FULL_THREADS) k_full_items(BatchParams P, const x265amd_me_job *jobs,
+                                                             const int *item_jobs, const FullItem *items, int n_items,
+                                                             FullBest *fb, int fb_stride, int lds_dwords)
+{
+    extern __shared__ uint32_t lds[];
+    int id = blockIdx.x;
+    if (id >= n_items)
+        return;
+    const FullItem &it = items[id];
+    if (it.count <= 0)
+        return;
+    if (W4 != 0)
+    {
+        full_item_body<W4 ? W4 : 1>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords);
+        return;
+    }
+    const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
+    switch (j0.w >> 2)
+    {
+    case 1:  full_item_body<1>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 2:  full_item_body<2>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 3:  full_item_body<3>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 4:  full_item_body<4>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 6:  full_item_body<6>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 8:  full_item_body<8>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 12: full_item_body<12>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 16: full_item_body<16>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    default: break;
+    }
+}
+
+// One item per job, built on the device: used when the job array only exists in device memory
+// and no plan was made for it.  Ineligible jobs get an empty item.
+__global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, int *item_jobs, FullItem *items)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n)
+        return;
+    const x265amd_me_job &j = jobs[id];
+    FullItem it;
+    it.first = id;
+    item_jobs[id] = id;
+    it.count = full_kernel_eligible(j, P.planes[P.enc_plane].bpp) ? 1 : 0;
+    const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+    const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1), W4 = j.w >> 2;
+    const int ND = XGe + W4;
+    it.y_lo = 0;
+    it.y_hi = ny;
+    it.slot = 0;
+    it.win_x0 = j.pu_x + j.mvmin_x;
+    it.win_y0 = j.pu_y + j.mvmin_y;
+    it.win_rows = 0;                               // staged per tile
+    it.win_nd = ND;
+    it.pitch = ND + ((((XGe >> 1) - ND) % 16) + 16) % 16;
+    items[id] = it;
+}
+
+} // namespace xa

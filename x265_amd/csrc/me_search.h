@@ -12,7 +12,8 @@
 
 namespace xa {
 
-// result of the dedicated exhaustive-search kernel for one job (raster-order first minimum)
+// Result of the dedicated exhaustive-search kernel for one job or one slab of candidate rows of
+// a job: the minimum of (cost, raster index) over the candidates it covered.
 struct FullBest
 {
     int32_t cost;       // SAD + mvcost of the best raster candidate; INT32_MAX if none
@@ -300,7 +301,7 @@ struct Search
     }
 
     // ---------------------------------------------------------------- the search
-    __device__ int run(const FullBest *fb, int &outx, int &outy)
+    __device__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
     {
         int merange = j.merange;
         W.ikind = j.icost;
@@ -569,11 +570,23 @@ struct Search
             {
                 // the exhaustive raster scan ran in its own kernel; its winner is the first
                 // minimum in raster order, which is what strict-`<` updates would have kept
-                if (fb->cost < bcost)
+                // combine the slabs: lowest cost, then lowest raster index
+                const int nxr = j.mvmax_x - j.mvmin_x + 1;
+                int fcost = 0x7fffffff, fidx = 0x7fffffff, fx = 0, fy = 0;
+                for (int s = 0; s < fb_stride; s++)
                 {
-                    bcost = fb->cost;
-                    bmx = fb->mvx;
-                    bmy = fb->mvy;
+                    int c = fb[s].cost, x = fb[s].mvx, y = fb[s].mvy;
+                    int idx = (y - j.mvmin_y) * nxr + (x - j.mvmin_x);
+                    if (c < fcost || (c == fcost && c != 0x7fffffff && idx < fidx))
+                    {
+                        fcost = c; fidx = idx; fx = x; fy = y;
+                    }
+                }
+                if (fcost < bcost)
+                {
+                    bcost = fcost;
+                    bmx = fx;
+                    bmy = fy;
                 }
                 int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
                 W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;

@@ -1,14 +1,18 @@
 // x265_amd C ABI (include/x265_amd.h): context, planes, MV cost tables and kernel launches.
 // Everything computes on the GPU; there is no host fallback.
 #include "me_kernels.h"
+#include "me_full.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 using namespace xa;
@@ -56,13 +60,22 @@ struct x265amd_ctx
     uint16_t    *d_cost = nullptr;        // 52 x 65536
     unsigned long long *d_evals = nullptr;
 
-    DevBuf jobs, results, fullbest, pairs, costs, stage;
+    DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
-    int    max_lds = 0;
     bool   timing = false;
     bool   timed_full = false, timed_any = false;
     hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+};
+
+// A planned job list: the jobs live in device memory together with the work-item plan of the
+// exhaustive kernel (which jobs share a staged window, how large jobs are cut into row slabs).
+struct x265amd_joblist
+{
+    int     n = 0, bpp = 1;
+    DevBuf  jobs, results, fb, items, item_jobs;
+    struct Launch { int first, count, lds_bytes, w4; };
+    std::vector<Launch> launches;          // one k_full_items launch per LDS size class
 };
 
 namespace {
@@ -212,11 +225,10 @@ int check_batch_planes(x265amd_ctx *c, int enc_plane, const int *ref_planes, int
     return 0;
 }
 
-// launch the exhaustive kernel (if the batch can contain eligible jobs) and the general kernel
-int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
-                  x265amd_me_result *d_out, bool maybe_full, int lds_bytes)
+constexpr int FULL_LDS_MAX = 64 * 1024;
+
+int record_start(x265amd_ctx *c)
 {
-    FullBest *fb = nullptr;
     if (c->timing)
     {
         for (int i = 0; i < 3; i++)
@@ -225,21 +237,18 @@ int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_m
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     }
     c->timed_full = false;
-    if (maybe_full && bpp == 1)
-    {
-        if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest)))
-            return rc;
-        fb = (FullBest*)c->fullbest.p;
-        hipLaunchKernelGGL(k_full_u8, dim3(n), dim3(256), lds_bytes, c->stream, P, d_jobs, n, fb, lds_bytes / 4);
-        HIPCHK(c, hipGetLastError());
-        c->timed_full = true;
-    }
+    return 0;
+}
+
+int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
+                   const FullBest *fb, int fb_stride, x265amd_me_result *d_out)
+{
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (bpp == 1)
-        hipLaunchKernelGGL(k_search<uint8_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
+        hipLaunchKernelGGL(k_search<uint8_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, fb_stride, d_out, c->d_evals);
     else
-        hipLaunchKernelGGL(k_search<uint16_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, d_out, c->d_evals);
+        hipLaunchKernelGGL(k_search<uint16_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, fb_stride, d_out, c->d_evals);
     HIPCHK(c, hipGetLastError());
     if (c->timing)
     {
@@ -249,7 +258,273 @@ int launch_search(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_m
     return 0;
 }
 
-constexpr int FULL_LDS_DEFAULT = 64 * 1024;
+// Unplanned path (job array only in device memory): one exhaustive work item per job, built on the device.
+int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
+                            x265amd_me_result *d_out)
+{
+    FullBest *fb = nullptr;
+    if (int rc = record_start(c)) return rc;
+    if (bpp == 1)
+    {
+        if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
+        if (int rc = ensure(c, c->items, (size_t)n * sizeof(FullItem))) return rc;
+        if (int rc = ensure(c, c->item_jobs, (size_t)n * sizeof(int))) return rc;
+        fb = (FullBest*)c->fullbest.p;
+        hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n,
+                           (int*)c->item_jobs.p, (FullItem*)c->items.p);
+        hipLaunchKernelGGL(k_full_items<0>, dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+                           (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
+        HIPCHK(c, hipGetLastError());
+        c->timed_full = true;
+    }
+    return launch_general(c, P, bpp, d_jobs, n, fb, 1, d_out);
+}
+
+// ---- exhaustive-kernel plan ------------------------------------------------------------------
+// LDS size classes: a class admits floor(160 KiB / bytes) workgroups per CU
+const int k_lds_classes[] = { 160 * 1024 / 6, 160 * 1024 / 5, 160 * 1024 / 4, 160 * 1024 / 3, FULL_LDS_MAX };
+constexpr int PLAN_CELL = 32;                  // small PUs whose origins share a 32x32 cell share a window
+constexpr double PLAN_SLAB_WORK = 16.0e6;      // target pixel-SADs per work item of a large PU
+
+int pitch_for(int nd, int xge)
+{
+    return nd + ((((xge >> 1) - nd) % 16) + 16) % 16;       // 2*pitch == xge (mod 32), pitch >= nd
+}
+
+struct PlannedItem { FullItem it; std::vector<int> members; int lds_bytes; };
+
+// window geometry + LDS need of an item holding `members` (indices into jobs) for rows [y_lo,y_hi)
+bool plan_item(const x265amd_me_job *jobs, const std::vector<int> &members, int y_lo, int y_hi, int slot, PlannedItem &out)
+{
+    const x265amd_me_job &j0 = jobs[members[0]];
+    const int W4 = j0.w >> 2, h = j0.h;
+    int x0 = INT32_MAX, y0 = INT32_MAX, y1 = INT32_MIN;
+    for (int m : members)
+    {
+        const x265amd_me_job &j = jobs[m];
+        x0 = std::min(x0, j.pu_x + j.mvmin_x);
+        y0 = std::min(y0, j.pu_y + j.mvmin_y + y_lo);
+        int ny = j.mvmax_y - j.mvmin_y + 1;
+        int yh = std::min(y_hi, ny);
+        y1 = std::max(y1, j.pu_y + j.mvmin_y + yh + h + 1);
+    }
+    int nd = 0;
+    for (int m : members)
+    {
+        const x265amd_me_job &j = jobs[m];
+        int nx = j.mvmax_x - j.mvmin_x + 1, xg = (nx + 3) >> 2, xge = xg + (xg & 1);
+        nd = std::max(nd, ((j.pu_x + j.mvmin_x - x0) >> 2) + xge + W4);
+    }
+    const int nx0 = j0.mvmax_x - j0.mvmin_x + 1, xg0 = (nx0 + 3) >> 2, xge0 = xg0 + (xg0 & 1);
+    FullItem &it = out.it;
+    it.first = 0;
+    it.count = (int)members.size();
+    it.y_lo = y_lo;
+    it.y_hi = y_hi;
+    it.slot = slot;
+    it.win_x0 = x0;
+    it.win_y0 = y0;
+    it.win_rows = y1 - y0;
+    it.win_nd = nd;
+    it.pitch = pitch_for(nd, xge0);
+    const int scratch_dw = h * W4 + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
+    const int n_scratch = it.count >= FULL_WAVES ? FULL_WAVES : 1;
+    out.lds_bytes = 4 * (n_scratch * scratch_dw + it.win_rows * it.pitch);
+    out.members = members;
+    return out.lds_bytes <= FULL_LDS_MAX;
+}
+
+void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vector<PlannedItem> &out)
+{
+    // a shared-window item must cover all candidate rows of its jobs in one staging pass
+    int nymax = 0;
+    for (int m : members)
+        nymax = std::max(nymax, jobs[m].mvmax_y - jobs[m].mvmin_y + 1);
+    PlannedItem pi;
+    if (members.size() > 1 && plan_item(jobs, members, 0, nymax, 0, pi) && pi.lds_bytes <= k_lds_classes[2])
+    {
+        out.push_back(pi);
+        return;
+    }
+    if (members.size() > 1)
+    {
+        size_t half = members.size() / 2;
+        plan_group(jobs, std::vector<int>(members.begin(), members.begin() + half), out);
+        plan_group(jobs, std::vector<int>(members.begin() + half, members.end()), out);
+        return;
+    }
+    // single job: cut into row slabs.  A slab of p candidate-row pairs is p * XGe lane tasks, executed
+    // in ceil(p * XGe / 256) passes of the workgroup: pick the slab count that wastes the fewest
+    // pass slots, preferring more (smaller) items when the waste is equal, as long as an item
+    // keeps a reasonable amount of work.
+    const x265amd_me_job &j = jobs[members[0]];
+    const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+    const int xg = (nx + 3) >> 2, xge = xg + (xg & 1);
+    const int pairs_total = (ny + 1) >> 1;
+    const double work = (double)nx * ny * j.w * j.h;
+    int best_s = 1;
+    long best_passes = -1;
+    for (int sl = 1; sl <= FB_STRIDE_PLAN && sl <= pairs_total; sl++)
+    {
+        if (sl > 1 && work / sl < PLAN_SLAB_WORK / 4)
+            break;
+        long passes = 0;
+        for (int k = 0; k < sl; k++)
+        {
+            int pk = pairs_total / sl + (k < pairs_total % sl ? 1 : 0);
+            passes += ((long)pk * xge + FULL_THREADS - 1) / FULL_THREADS;
+        }
+        if (best_passes < 0 || passes <= best_passes)
+        {
+            best_passes = passes;
+            best_s = sl;
+        }
+    }
+    for (int slabs = best_s; slabs <= FB_STRIDE_PLAN; slabs++)
+    {
+        std::vector<PlannedItem> tmp;
+        bool ok = true;
+        int y = 0;
+        for (int k = 0; k < slabs && ok; k++)
+        {
+            int pk = pairs_total / slabs + (k < pairs_total % slabs ? 1 : 0);
+            int y1 = std::min(ny, y + 2 * pk);
+            PlannedItem p2;
+            ok = plan_item(jobs, members, y, y1, k, p2);
+            tmp.push_back(p2);
+            y = y1;
+        }
+        if (ok)
+        {
+            out.insert(out.end(), tmp.begin(), tmp.end());
+            return;
+        }
+    }
+    // does not fit even as FB_STRIDE_PLAN slabs: one item, tiled inside the kernel (win_rows = 0)
+    PlannedItem p3;
+    plan_item(jobs, members, 0, ny, 0, p3);
+    p3.it.win_rows = 0;
+    p3.it.win_y0 = j.pu_y + j.mvmin_y;
+    p3.lds_bytes = FULL_LDS_MAX;
+    out.push_back(p3);
+}
+
+int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs, int n, int bpp)
+{
+    L->n = n;
+    L->bpp = bpp;
+    if (int rc = ensure(c, L->jobs, (size_t)n * sizeof(x265amd_me_job))) return rc;
+    if (int rc = ensure(c, L->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
+    HIPCHK(c, hipMemcpyAsync(L->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
+
+    std::vector<PlannedItem> planned;
+    if (bpp == 1)
+    {
+        std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
+        for (int i = 0; i < n; i++)
+        {
+            const x265amd_me_job &j = jobs[i];
+            if (!full_kernel_eligible(j, bpp))
+                continue;
+            if (j.w * j.h <= 256)
+            {
+                auto fl = [](int v) { return v >= 0 ? v / PLAN_CELL : -((-v + PLAN_CELL - 1) / PLAN_CELL); };
+                groups[std::make_tuple((int)j.ref_idx, (int)j.w | (j.h << 8), fl(j.pu_y), fl(j.pu_x),
+                                       (j.pu_x + j.mvmin_x) & 3, 0)].push_back(i);
+            }
+            else
+                plan_group(jobs, std::vector<int>(1, i), planned);
+        }
+        for (auto &g : groups)
+            plan_group(jobs, g.second, planned);
+    }
+    if (!planned.empty())
+    {
+        // class = smallest LDS size that holds the item; launches ordered largest class first
+        auto cls = [](const PlannedItem &p) {
+            for (int k = 0; k < 5; k++)
+                if (p.lds_bytes <= k_lds_classes[k])
+                    return k;
+            return 4;
+        };
+        auto w4of = [&](const PlannedItem &p) { return jobs[p.members[0]].w >> 2; };
+        // launch order: widest PUs / largest LDS class first (longest work items start first)
+        std::stable_sort(planned.begin(), planned.end(), [&](const PlannedItem &a, const PlannedItem &b) {
+            return std::make_pair(w4of(a), cls(a)) > std::make_pair(w4of(b), cls(b)); });
+        std::vector<FullItem> items;
+        std::vector<int> item_jobs;
+        for (PlannedItem &p : planned)
+        {
+            p.it.first = (int)item_jobs.size();
+            item_jobs.insert(item_jobs.end(), p.members.begin(), p.members.end());
+            items.push_back(p.it);
+        }
+        for (size_t a = 0; a < planned.size();)
+        {
+            size_t b = a;
+            int k = cls(planned[a]), w4 = w4of(planned[a]);
+            while (b < planned.size() && cls(planned[b]) == k && w4of(planned[b]) == w4)
+                b++;
+            L->launches.push_back({ (int)a, (int)(b - a), k_lds_classes[k] & ~3, w4 });
+            a = b;
+        }
+        std::vector<FullBest> fb((size_t)n * FB_STRIDE_PLAN);
+        for (FullBest &f : fb)
+        {
+            f.cost = 0x7fffffff;
+            f.mvx = f.mvy = 0;
+        }
+        if (int rc = ensure(c, L->fb, fb.size() * sizeof(FullBest))) return rc;
+        if (int rc = ensure(c, L->items, items.size() * sizeof(FullItem))) return rc;
+        if (int rc = ensure(c, L->item_jobs, item_jobs.size() * sizeof(int))) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->fb.p, fb.data(), fb.size() * sizeof(FullBest), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L->items.p, items.data(), items.size() * sizeof(FullItem), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L->item_jobs.p, item_jobs.data(), item_jobs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the host vectors die here
+    return 0;
+}
+
+void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
+{
+    hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs };
+    for (DevBuf *b : bufs)
+        if (b->p)
+            hipFree(b->p);
+    delete L;
+}
+
+int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
+{
+    if (int rc = record_start(c)) return rc;
+    for (const x265amd_joblist::Launch &la : L->launches)
+    {
+#define XA_LAUNCH_FULL(W4V)                                                                                   \
+        hipLaunchKernelGGL(k_full_items<W4V>, dim3(la.count), dim3(FULL_THREADS), la.lds_bytes, c->stream, P, \
+                           (const x265amd_me_job*)L->jobs.p, (const int*)L->item_jobs.p,                      \
+                           (const FullItem*)L->items.p + la.first, la.count, (FullBest*)L->fb.p, FB_STRIDE_PLAN, \
+                           la.lds_bytes / 4)
+        switch (la.w4)
+        {
+        case 1:  XA_LAUNCH_FULL(1); break;
+        case 2:  XA_LAUNCH_FULL(2); break;
+        case 3:  XA_LAUNCH_FULL(3); break;
+        case 4:  XA_LAUNCH_FULL(4); break;
+        case 6:  XA_LAUNCH_FULL(6); break;
+        case 8:  XA_LAUNCH_FULL(8); break;
+        case 12: XA_LAUNCH_FULL(12); break;
+        case 16: XA_LAUNCH_FULL(16); break;
+        default: XA_LAUNCH_FULL(0); break;
+        }
+#undef XA_LAUNCH_FULL
+        HIPCHK(c, hipGetLastError());
+        c->timed_full = true;
+    }
+    return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
+                          L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
+                          (x265amd_me_result*)L->results.p);
+}
 
 } // namespace
 
@@ -301,14 +576,19 @@ int x265amd_create(int device, x265amd_ctx **out)
         }
     hipMemset(c->d_evals, 0, sizeof(unsigned long long));
     // the exhaustive kernel uses up to 64 KiB of dynamic LDS
-    e = hipFuncSetAttribute((const void*)k_full_u8, hipFuncAttributeMaxDynamicSharedMemorySize, FULL_LDS_DEFAULT);
+    const void *full_kernels[] = { (const void*)k_full_items<0>, (const void*)k_full_items<1>, (const void*)k_full_items<2>,
+                                   (const void*)k_full_items<3>, (const void*)k_full_items<4>, (const void*)k_full_items<6>,
+                                   (const void*)k_full_items<8>, (const void*)k_full_items<12>, (const void*)k_full_items<16> };
+    e = hipSuccess;
+    for (const void *k : full_kernels)
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FULL_LDS_MAX);
     if (e != hipSuccess)
     {
         fprintf(stderr, "x265amd_create: kernels not loadable on this device: %s\n", hipGetErrorString(e));
         delete c;
         return X265AMD_ERR_NO_DEVICE;
     }
-    c->max_lds = FULL_LDS_DEFAULT;
     *out = c;
     return X265AMD_OK;
 }
@@ -322,7 +602,7 @@ void x265amd_destroy(x265amd_ctx *c)
     for (int i = 0; i < MAX_PLANES; i++)
         if (c->used[i] && c->owned[i])
             hipFree(c->owned[i]);
-    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage };
+    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -485,16 +765,23 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
     bool any_full = false;
     if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
     if (int rc = sync_planes(c)) return rc;
-    if (int rc = ensure(c, c->jobs, (size_t)n * sizeof(x265amd_me_job))) return rc;
-    if (int rc = ensure(c, c->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
-    BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
-    if (int rc = launch_search(c, P, c->h_planes[enc_plane].bpp, (const x265amd_me_job*)c->jobs.p, n,
-                               (x265amd_me_result*)c->results.p, any_full, c->max_lds))
-        return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->results.p, (size_t)n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    x265amd_joblist *L = new x265amd_joblist;
+    int rc = joblist_build(c, L, jobs, n, c->h_planes[enc_plane].bpp);
+    if (!rc)
+    {
+        BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
+        rc = joblist_launch(c, L, P);
+    }
+    if (!rc)
+    {
+        hipError_t e = hipMemcpyAsync(out, L->results.p, (size_t)n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess)
+            rc = fail(c, X265AMD_ERR_HIP, "result download", e);
+    }
+    joblist_free(c, L);
+    return rc;
 }
 
 int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
@@ -509,7 +796,64 @@ int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = sync_planes(c)) return rc;
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
-    return launch_search(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out, true, c->max_lds);
+    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out);
+}
+
+int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,
+                           x265amd_joblist **out)
+{
+    if (!c || !jobs || !out || n <= 0 || (bytes_per_px != 1 && bytes_per_px != 2))
+        return X265AMD_ERR_INVALID;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    bool any_full = false;
+    if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
+    x265amd_joblist *L = new x265amd_joblist;
+    int rc = joblist_build(c, L, jobs, n, bytes_per_px);
+    if (rc)
+    {
+        joblist_free(c, L);
+        return rc;
+    }
+    *out = L;
+    return 0;
+}
+
+int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs,
+                        x265amd_me_result *out)
+{
+    if (!c || !L)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (c->h_planes[enc_plane].bpp != L->bpp)
+        return fail(c, X265AMD_ERR_INVALID, "job list was planned for a different pixel size");
+    if (int rc = sync_planes(c)) return rc;
+    BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
+    if (int rc = joblist_launch(c, L, P)) return rc;
+    if (out)
+    {
+        HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *L)
+{
+    return L ? (const x265amd_me_result*)L->results.p : nullptr;
+}
+
+int x265amd_joblist_destroy(x265amd_ctx *c, x265amd_joblist *L)
+{
+    if (!c || !L)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    joblist_free(c, L);
+    return 0;
 }
 
 int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
