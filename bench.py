@@ -147,10 +147,10 @@ def main():
     jl_full = eng.make_joblist(full_jobs)
     eng.set_timing(True)
 
+    from x265_amd import dist as xd
+
     def step(jl):
-        if world > 1:
-            dist.broadcast(ref_t, src=0)          # reference plane: rank 0 -> all, RCCL over xGMI
-            torch.cuda.current_stream().synchronize()   # the search runs on the engine's own stream
+        xd.broadcast_plane(ref_t, src=0, engine=eng)   # reference plane: rank 0 -> all (RCCL over xGMI when N > 1)
         jl.run(enc_id, [ref_id], fetch=False)
 
     def barrier():

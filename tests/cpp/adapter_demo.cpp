@@ -1,0 +1,91 @@
+// Drives the C++ adapter the way an encoder call site would and prints the results as text:
+//   adapter_demo <width> <height> <margin> <enc.raw> <ref.raw>
+// Planes are padded 8-bit luma (stride = width + 2*margin).  Used by tests/test_adapter_cpp.py.
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../../x265_amd/host/x265_amd_host.hpp"
+
+typedef unsigned char pixel;
+// a primitive table with the reference's slot types (common/primitives.h:180-184, 240-250)
+typedef int  (*pixelcmp_t)(pixel *fenc, intptr_t fencstride, pixel *fref, intptr_t frefstride);
+typedef void (*pixelcmp_x4_t)(pixel *fenc, pixel *fref0, pixel *fref1, pixel *fref2, pixel *fref3, intptr_t frefstride, int *res);
+typedef void (*pixelcmp_x3_t)(pixel *fenc, pixel *fref0, pixel *fref1, pixel *fref2, intptr_t frefstride, int *res);
+struct EncoderPrimitives
+{
+    pixelcmp_t sad[64];
+    pixelcmp_x3_t sad_x3[64];
+    pixelcmp_x4_t sad_x4[64];
+    pixelcmp_t satd[64];
+    pixelcmp_t sa8d_inter[64];
+    pixelcmp_t sa8d[5];
+};
+
+static std::vector<pixel> slurp(const char *path, size_t n)
+{
+    std::vector<pixel> v(n);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(v.data(), 1, n, f) != n) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage\n"); return 2; }
+    int W = atoi(argv[1]), H = atoi(argv[2]), M = atoi(argv[3]);
+    int stride = W + 2 * M;
+    size_t n = (size_t)stride * (H + 2 * M);
+    std::vector<pixel> enc = slurp(argv[4], n), ref = slurp(argv[5], n);
+    try
+    {
+        x265amd::Context ctx(0);
+        x265amd::ReferencePlanes pe = ctx.uploadPlane(enc.data(), W, H, M, M, stride, 1, 8);
+        x265amd::ReferencePlanes pr = ctx.uploadPlane(ref.data(), W, H, M, M, stride, 1, 8);
+        x265amd::MotionEstimate me(ctx);
+        me.setSourcePlane(pe);
+        me.setQP(30);
+        // (1) the reference's per-PU call sequence, all five methods
+        for (int method = 0; method < 5; method++)
+        {
+            me.setSearchMethod(method);
+            me.setSubpelRefine(5);
+            me.setSourcePU(32 * stride + 48, 16, 16);
+            x265amd::MV mvc[2] = { x265amd::MV(8, -4), x265amd::MV(-12, 6) }, out;
+            int cost = me.motionEstimate(&pr, x265amd::MV(-16, -16), x265amd::MV(16, 16), x265amd::MV(5, -3), 2, mvc, 16, out);
+            printf("single %d %d %d %d\n", method, out.x, out.y, cost);
+        }
+        // (2) batched: one row of 16x16 PUs queued, then flushed
+        me.setSearchMethod(1);
+        me.setSubpelRefine(2);
+        int cnt = 0;
+        for (int x = 0; x + 16 <= W; x += 16, cnt++)
+        {
+            me.setSourcePUxy(x, 16, 16, 16);
+            me.queue(&pr, x265amd::MV(-24, -16), x265amd::MV(24, 16), x265amd::MV(0, 0), 0, NULL, 24);
+        }
+        const std::vector<x265amd_me_result> &r = me.flush();
+        for (int i = 0; i < cnt; i++)
+            printf("batch %d %d %d %d\n", i, r[i].mvx, r[i].mvy, r[i].cost);
+        // (3) bufSAD / bufSATD / bufSA8D
+        me.setSourcePUxy(64, 32, 32, 32);
+        printf("buf %d %d %d\n", me.bufSAD(pr, 60, 35), me.bufSATD(pr, 60, 35), me.bufSA8D(pr, 60, 35));
+        // (4) the primitive table hook
+        EncoderPrimitives prim;
+        if (x265amd::Setup_HIP_Primitives(prim, 0, 1)) { fprintf(stderr, "setup primitives failed\n"); return 3; }
+        pixel *e0 = enc.data() + (size_t)M * stride + M, *r0 = ref.data() + (size_t)M * stride + M;
+        int res[4];
+        prim.sad_x4[27](e0, r0, r0 + 1, r0 + 2, r0 + 3, stride, res);   // PARTITION_16x16 == 27; fenc stride is 64 by contract
+        printf("prim %d %d %d %d %d\n", prim.sad[27](e0, stride, r0 + 5, stride), prim.satd[27](e0, stride, r0 + 5, stride),
+               prim.sa8d_inter[27](e0, stride, r0 + 5, stride), res[0], res[3]);
+        ctx.releasePlane(pe);
+        ctx.releasePlane(pr);
+    }
+    catch (const std::exception &e)
+    {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

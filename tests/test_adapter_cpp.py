@@ -1,0 +1,61 @@
+"""The C++ host mirror of the reference's MotionEstimate interface (x265_amd/host/x265_amd_host.hpp)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "tests", "cpp", "adapter_demo")
+
+
+def test_adapter_header_compiles():
+    """header + demo driver compile against the C ABI (syntax only: no GPU needed)"""
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", src])
+
+
+@pytest.mark.gpu
+def test_adapter_results_match_oracle(oracle, tmp_path):
+    from x265_amd import jobs as J, synth
+    assert os.path.exists(DEMO), "build it with __graft_entry__.build()"
+    W, H, M = 256, 128, synth.MARGIN
+    fr = synth.make_sequence(W, H, 2, seed=404)
+    e, r = str(tmp_path / "enc.raw"), str(tmp_path / "ref.raw")
+    fr[0].tofile(e)
+    fr[1].tofile(r)
+    out = subprocess.run([DEMO, str(W), str(H), str(M), e, r], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [l.split() for l in out.stdout.strip().splitlines()]
+    stride = W + 2 * M
+    # (1) single calls
+    for l in [l for l in lines if l[0] == "single"]:
+        method = int(l[1])
+        jb = J.make_jobs(W, H, [48], [32], 16, 16, method=method, subme=5, merange=16, qp=30, qmvp=(5, -3),
+                         mvc=[[8, -4], [-12, 6]])
+        jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -16, -16, 16, 16
+        exp, _ = oracle.search(fr[0], [fr[1]], jb)
+        assert (int(l[2]), int(l[3]), int(l[4])) == (int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])), l
+    # (2) batch
+    xs = np.arange(0, W - 15, 16)
+    jb = J.make_jobs(W, H, xs, np.full_like(xs, 16), 16, 16, method=J.HEX, subme=2, merange=24, qp=30)
+    jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -24, -16, 24, 16
+    exp, _ = oracle.search(fr[0], [fr[1]], jb)
+    got = [l for l in lines if l[0] == "batch"]
+    assert len(got) == len(jb)
+    for l, ex in zip(got, exp):
+        assert (int(l[2]), int(l[3]), int(l[4])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"]))
+    # (3) buf costs: PU (64,32) 32x32 vs ref block at (60,35)
+    flat0, flat1 = fr[0].reshape(-1), fr[1].reshape(-1)
+    eo, ro = (32 + M) * stride + 64 + M, (35 + M) * stride + 60 + M
+    part = J.partition_from_sizes(32, 32)
+    buf = [l for l in lines if l[0] == "buf"][0]
+    assert [int(v) for v in buf[1:]] == [oracle.cmp(k, part, flat0, eo, stride, flat1, ro, stride) for k in (0, 1, 2)]
+    # (4) primitive table: 16x16 at plane origin, ref at +5; sad_x4 reads fenc with stride 64
+    o0 = M * stride + M
+    p16 = J.partition_from_sizes(16, 16)
+    prim = [l for l in lines if l[0] == "prim"][0]
+    exp3 = [oracle.cmp(k, p16, flat0, o0, stride, flat1, o0 + 5, stride) for k in (0, 1, 2)]
+    x4 = oracle.sad_xn(4, p16, flat0, o0, flat1, [o0, o0 + 1, o0 + 2, o0 + 3], stride)
+    assert [int(v) for v in prim[1:]] == exp3 + [int(x4[0]), int(x4[3])]

@@ -1,0 +1,209 @@
+// Host-side C++ mirror of the reference's motion-estimation interface, on top of the C ABI
+// (include/x265_amd.h).  Same method names, argument meaning and call order as
+//   class MotionEstimate        (reference: source/encoder/motion.h:35-112)
+//   struct MV                   (reference: source/common/mv.h:36-100)
+//   Setup_*_Primitives(p, ...)  (reference: source/common/primitives.h:306-308)
+// so that the call sites in TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2332-2451)
+// and Lookahead::estimateCUCost (encoder/slicetype.cpp:354-407) can switch over one call at a time.
+//
+// Two ways to search:
+//   * motionEstimate(...)  -- the reference's synchronous per-PU call; runs a batch of one job;
+//   * queue(...) / flush() -- collect the jobs of a row / frame, run them as one batch, read the
+//     per-PU MV/cost field back.  This is the path that makes the GPU worthwhile.
+#pragma once
+
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/x265_amd.h"
+
+namespace x265amd {
+
+struct MV
+{
+    int16_t x, y;
+    MV() : x(0), y(0) {}
+    MV(int16_t x_, int16_t y_) : x(x_), y(y_) {}
+    bool operator==(const MV &o) const { return x == o.x && y == o.y; }
+    bool operator!=(const MV &o) const { return !(*this == o); }
+    MV operator<<(int i) const { return MV((int16_t)(x << i), (int16_t)(y << i)); }
+    MV operator>>(int i) const { return MV((int16_t)(x >> i), (int16_t)(y >> i)); }
+    MV roundToFPel() const { return MV((int16_t)(x + 2), (int16_t)(y + 2)) >> 2; }
+    MV toQPel() const { return *this << 2; }
+};
+
+// A registered plane stands in for ReferencePlanes::fpelPlane / lumaStride (common/reference.h:36-53)
+struct ReferencePlanes
+{
+    int plane_id;
+    int lumaStride;
+};
+
+class Context
+{
+public:
+    explicit Context(int device = 0)
+    {
+        int rc = x265amd_create(device, &m_ctx);
+        if (rc)
+            throw std::runtime_error("x265amd_create failed with " + std::to_string(rc));
+    }
+    ~Context() { x265amd_destroy(m_ctx); }
+    Context(const Context&) = delete;
+    Context &operator=(const Context&) = delete;
+
+    x265amd_ctx *get() const { return m_ctx; }
+
+    // Upload a TComPicYuv-style padded luma plane (host memory).
+    ReferencePlanes uploadPlane(const void *base, int width, int height, int marginX, int marginY,
+                                intptr_t stride, int bytesPerPixel, int bitDepth)
+    {
+        ReferencePlanes r;
+        check(x265amd_plane_upload(m_ctx, base, width, height, marginX, marginY, stride, bytesPerPixel, bitDepth, &r.plane_id));
+        r.lumaStride = (int)stride;
+        return r;
+    }
+    void releasePlane(const ReferencePlanes &p) { check(x265amd_plane_release(m_ctx, p.plane_id)); }
+
+    void check(int rc) const
+    {
+        if (rc)
+            throw std::runtime_error(std::string("x265_amd: ") + x265amd_last_error(m_ctx));
+    }
+
+private:
+    x265amd_ctx *m_ctx = nullptr;
+};
+
+class MotionEstimate
+{
+public:
+    explicit MotionEstimate(Context &ctx) : m_ctx(ctx) {}
+
+    void setSearchMethod(int i) { m_method = i; }                 // motion.h:72
+    void setSubpelRefine(int i) { m_subme = i; }                  // motion.h:74
+    void setQP(unsigned qp) { m_qp = qp; }                        // bitcost.h:41
+    void setSourcePlane(const ReferencePlanes &enc) { m_enc = enc; }   // motion.h:78-82
+    void setSourcePU(int offset, int pwidth, int pheight)         // motion.h:84: offset = y*stride + x
+    {
+        // floor division so that PUs in the padded border (negative y) map back correctly
+        int y = offset >= 0 ? offset / m_enc.lumaStride : -((-offset + m_enc.lumaStride - 1) / m_enc.lumaStride);
+        int x = offset - y * m_enc.lumaStride;
+        if (x > m_enc.lumaStride / 2) { x -= m_enc.lumaStride; y += 1; }
+        m_puX = x; m_puY = y; m_w = pwidth; m_h = pheight;
+    }
+    void setSourcePUxy(int x, int y, int pwidth, int pheight) { m_puX = x; m_puY = y; m_w = pwidth; m_h = pheight; }
+
+    // bufSAD / bufSATD / bufSA8D (motion.h:89-93): cost of the current PU against a block of `ref`
+    int bufSAD(const ReferencePlanes &ref, int x, int y)  { return bufCost(X265AMD_SAD, ref, x, y); }
+    int bufSATD(const ReferencePlanes &ref, int x, int y) { return bufCost(X265AMD_SATD, ref, x, y); }
+    int bufSA8D(const ReferencePlanes &ref, int x, int y) { return bufCost(X265AMD_SA8D, ref, x, y); }
+
+    // motion.h:95 -- synchronous, one job
+    int motionEstimate(const ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp,
+                       int numCandidates, const MV *mvc, int merange, MV &outQMv)
+    {
+        x265amd_me_job j = makeJob(mvmin, mvmax, qmvp, numCandidates, mvc, merange);
+        x265amd_me_result r;
+        int refs[1] = { ref->plane_id };
+        m_ctx.check(x265amd_me_search_batch(m_ctx.get(), m_enc.plane_id, refs, 1, &j, 1, &r));
+        outQMv = MV(r.mvx, r.mvy);
+        return r.cost;
+    }
+
+    // batched form: same arguments, result delivered by flush(); returns the job's index
+    int queue(const ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp,
+              int numCandidates, const MV *mvc, int merange)
+    {
+        x265amd_me_job j = makeJob(mvmin, mvmax, qmvp, numCandidates, mvc, merange);
+        int slot = -1;
+        for (size_t i = 0; i < m_refs.size(); i++)
+            if (m_refs[i] == ref->plane_id)
+                slot = (int)i;
+        if (slot < 0)
+        {
+            if (m_refs.size() >= X265AMD_MAX_REFS)
+                throw std::runtime_error("x265_amd: too many reference planes in one batch");
+            slot = (int)m_refs.size();
+            m_refs.push_back(ref->plane_id);
+        }
+        j.ref_idx = (uint8_t)slot;
+        m_jobs.push_back(j);
+        return (int)m_jobs.size() - 1;
+    }
+    // run everything queued since the last flush (all against the current source plane)
+    const std::vector<x265amd_me_result> &flush()
+    {
+        m_results.resize(m_jobs.size());
+        if (!m_jobs.empty())
+            m_ctx.check(x265amd_me_search_batch(m_ctx.get(), m_enc.plane_id, m_refs.data(), (int)m_refs.size(),
+                                                m_jobs.data(), (int)m_jobs.size(), m_results.data()));
+        m_jobs.clear();
+        m_refs.clear();
+        return m_results;
+    }
+
+    // BitCost::bitcost(mv) relative to the last predictor (bitcost.h:49-53)
+    int bitcost(const MV &mv) const { return x265amd_bitcost(m_ctx.get(), m_mvp.x, m_mvp.y, mv.x, mv.y); }
+
+private:
+    int bufCost(int kind, const ReferencePlanes &ref, int x, int y)
+    {
+        x265amd_block_pair p = { m_enc.plane_id, m_puX, m_puY, ref.plane_id, x, y };
+        int32_t out;
+        m_ctx.check(x265amd_cost_batch(m_ctx.get(), kind, m_w, m_h, 1, &p, &out));
+        return out;
+    }
+    x265amd_me_job makeJob(const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc, const MV *mvc, int merange)
+    {
+        x265amd_me_job j = x265amd_me_job();
+        j.pu_x = m_puX; j.pu_y = m_puY; j.w = (int16_t)m_w; j.h = (int16_t)m_h;
+        j.mvmin_x = mvmin.x; j.mvmin_y = mvmin.y; j.mvmax_x = mvmax.x; j.mvmax_y = mvmax.y;
+        j.qmvp_x = qmvp.x; j.qmvp_y = qmvp.y;
+        j.merange = (int16_t)merange;
+        j.method = (uint8_t)m_method; j.subme = (uint8_t)m_subme; j.qp = (uint8_t)m_qp;
+        j.numc = (uint8_t)(numc > X265AMD_MAX_MVC ? X265AMD_MAX_MVC : numc);
+        for (int i = 0; i < j.numc; i++) { j.mvc[i][0] = mvc[i].x; j.mvc[i][1] = mvc[i].y; }
+        j.icost = X265AMD_SAD;
+        m_mvp = qmvp;
+        return j;
+    }
+
+    Context &m_ctx;
+    ReferencePlanes m_enc = { -1, 0 };
+    int m_method = 3, m_subme = 5;          // the reference's defaults (motion.cpp:82-85)
+    unsigned m_qp = 32;
+    int m_puX = 0, m_puY = 0, m_w = 0, m_h = 0;
+    MV m_mvp;
+    std::vector<x265amd_me_job> m_jobs;
+    std::vector<int> m_refs;
+    std::vector<x265amd_me_result> m_results;
+};
+
+// Overwrite the ME-related slots of a primitive table laid out like the reference's
+// EncoderPrimitives (sad/sad_x3/sad_x4/satd/sa8d_inter [64], sa8d[5]) the way
+// Setup_Vector_Primitives / Setup_Assembly_Primitives do (common/primitives.cpp:129-139).
+// `Table` is the encoder's struct; its slot types only differ from ours in `pixel*` vs `void*`.
+template <class Table>
+int Setup_HIP_Primitives(Table &p, int device, int bytesPerPixel)
+{
+    static x265amd_primitives t;
+    int rc = x265amd_setup_primitives(&t, device, bytesPerPixel);
+    if (rc)
+        return rc;
+    for (int i = 0; i < 64; i++)
+    {
+        p.sad[i] = reinterpret_cast<decltype(p.sad[i])>(t.sad[i]);
+        p.sad_x3[i] = reinterpret_cast<decltype(p.sad_x3[i])>(t.sad_x3[i]);
+        p.sad_x4[i] = reinterpret_cast<decltype(p.sad_x4[i])>(t.sad_x4[i]);
+        p.satd[i] = reinterpret_cast<decltype(p.satd[i])>(t.satd[i]);
+        p.sa8d_inter[i] = reinterpret_cast<decltype(p.sa8d_inter[i])>(t.sa8d_inter[i]);
+    }
+    for (int i = 0; i < 5; i++)
+        p.sa8d[i] = reinterpret_cast<decltype(p.sa8d[i])>(t.sa8d[i]);
+    return 0;
+}
+
+} // namespace x265amd
