@@ -14,7 +14,7 @@ from .jobs import JOB_DTYPE, RESULT_DTYPE
 from .synth import MARGIN
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx265amd.so")
+LIB_PATH = os.environ.get("X265AMD_LIB", os.path.join(_HERE, "libx265amd.so"))
 
 SAD, SATD, SA8D = 0, 1, 2
 

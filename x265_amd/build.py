@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "x265_amd.hip")
-OUT = os.path.join(HERE, "libx265amd.so")
+OUT = os.environ.get("X265AMD_OUT", os.path.join(HERE, "libx265amd.so"))
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("me_device.h", "me_search.h", "me_kernels.h", "me_full.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "x265_amd.h")]
 
@@ -25,6 +25,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off",           # the MV cost table must round exactly like the reference build
+           *os.environ.get("X265AMD_EXTRA_FLAGS", "").split(),
            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
            "-o", OUT, SRC]
     if verbose:

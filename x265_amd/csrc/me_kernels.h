@@ -15,10 +15,12 @@ struct BatchParams
     int32_t          enc_plane;
     int32_t          ref_planes[X265AMD_MAX_REFS];
     int32_t          n_refs;
+    int32_t          flags;               // JF_* bits applied to every job (tuning aids)
 };
 
 // Does the dedicated exhaustive kernel handle this job?  (8-bit pixels, SAD metric, bounded range)
-__device__ __host__ inline bool full_kernel_eligible(const x265amd_me_job &j, int bpp)
+template <class J>
+__device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
 {
     int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     return j.method == X265AMD_FULL && j.icost == X265AMD_SAD && bpp == 1 &&
@@ -26,38 +28,35 @@ __device__ __host__ inline bool full_kernel_eligible(const x265amd_me_job &j, in
 }
 
 // ------------------------------------------------------------------------------------------
-// General search: one wavefront per job, any method / sub-pel level / pixel type.
-template <typename PIX>
-__global__ void __launch_bounds__(64) k_search(BatchParams P, const x265amd_me_job *jobs, int n,
-                                               const FullBest *fb, int fb_stride, x265amd_me_result *out,
-                                               unsigned long long *evals)
+// General search: any method / sub-pel level / pixel type.  Jobs come in three classes by PU area,
+// sized so that one pass of the job's lanes covers the largest PU of the class: up to 256 pixels
+// on one wavefront, up to 1024 on four, larger on sixteen.  `idx` (optional) lists the jobs of
+// this launch; without it every job is visited and those of the other classes are skipped.
+constexpr int JOB_CLASSES = 3;
+__device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
+
+template <class L>
+__global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,
+                                                  const FullBest *fb, int fb_stride, x265amd_me_result *out,
+                                                  unsigned long long *evals)
 {
-    __shared__ uint32_t s_fenc[1024 * PixTraits<PIX>::DW];
-    __shared__ int s_roff[1024];
-    int id = blockIdx.x;
-    if (id >= n)
+    __shared__ __align__(16) L lds;
+    if ((int)blockIdx.x >= n)
         return;
-    const x265amd_me_job &j = jobs[id];
+    const int id = idx ? idx[blockIdx.x] : (int)blockIdx.x;
+    JobRegs j;
+    j.load(jobs + id);
+    if (job_class(j.w, j.h) != cls)
+        return;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
-    Wave<PIX> W;
-    W.fenc = s_fenc;
-    W.roff = s_roff;
-    W.cost = P.cost[j.qp];
-    W.bind(enc, ref, j.pu_x, j.pu_y, j.pu_x, j.pu_y, j.w, j.h, true);
-    Search<PIX> S(W, j);
+    Wave<L> W;
+    W.bind(lds, enc, ref, j.pu_x, j.pu_y, j.pu_x, j.pu_y, j.w, j.h, P.cost[j.qp], P.flags);
+    Search<L> S(W, j);
     int ox, oy;
-    const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(PIX))) ? fb + (size_t)id * fb_stride : nullptr;
-    int cost = S.run(f, fb_stride, ox, oy);
-    if (W.lane == 0)
-    {
-        x265amd_me_result r;
-        r.mvx = (int16_t)ox;
-        r.mvy = (int16_t)oy;
-        r.cost = cost;
-        out[id] = r;
-        atomicAdd(evals, (unsigned long long)W.evals);
-    }
+    const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(typename L::PIX))) ? fb + (size_t)id * fb_stride : nullptr;
+    int cost = S.run(f, fb_stride, P.flags, ox, oy);
+    Dev<L>::publish(W.base, out + id, ox, oy, cost, evals);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -66,19 +65,17 @@ template <typename PIX>
 __global__ void __launch_bounds__(64) k_cost(const PlaneDesc *planes, int kind, int w, int h,
                                              const x265amd_block_pair *pairs, int n, int32_t *out)
 {
-    __shared__ uint32_t s_fenc[1024 * PixTraits<PIX>::DW];
-    __shared__ int s_roff[1024];
+    typedef JobLds<PIX, 1, 1024> L;
+    __shared__ __align__(16) L lds;
     int id = blockIdx.x;
     if (id >= n)
         return;
     const x265amd_block_pair &p = pairs[id];
-    Wave<PIX> W;
-    W.fenc = s_fenc;
-    W.roff = s_roff;
-    W.cost = nullptr;
-    W.bind(planes[p.enc_plane], planes[p.ref_plane], p.enc_x, p.enc_y, p.ref_x, p.ref_y, w, h, false);
-    int c = W.template cost_kind<PRED_INT>(kind, W.off_of(0, 0), 0, 0);
-    if (W.lane == 0)
+    Wave<L> W;
+    W.bind(lds, planes[p.enc_plane], planes[p.ref_plane], p.enc_x, p.enc_y, p.ref_x, p.ref_y, w, h, nullptr,
+           JF_NO_WINDOW | JF_NO_SLICES);
+    int c = W.cost_direct(kind);
+    if (W.tid == 0)
         out[id] = c;
 }
 

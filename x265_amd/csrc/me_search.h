@@ -20,27 +20,62 @@ struct FullBest
     int16_t mvx, mvy;   // full-pel
 };
 
-__constant__ int8_t c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-__constant__ int8_t c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
-__constant__ int8_t c_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+// (32-bit entries: uniform lookups then compile to scalar loads, which have no byte form on this target)
+__constant__ int c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__constant__ int c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__constant__ int c_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
                                       { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
-__constant__ int8_t c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+__constant__ int c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
                                               { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
 // workload[] (motion.cpp:51-60): hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd
-__constant__ int8_t c_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+__constant__ int c_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
                                          { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
-__constant__ uint8_t c_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+__constant__ int c_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
 
 #define XA_S16(v) ((int)(int16_t)(v))
 
-template <typename PIX>
+// A job unpacked into scalars.  (A by-value copy of the packed struct would be indexed dynamically
+// through mvc[] and therefore live in per-lane scratch memory; these fields stay in scalar registers.)
+struct JobRegs
+{
+    int pu_x, pu_y, w, h, mvmin_x, mvmin_y, mvmax_x, mvmax_y, qmvp_x, qmvp_y;
+    int merange, method, subme, qp, numc, ref_idx, icost;
+    int mvc[X265AMD_MAX_MVC][2];
+
+    __device__ __forceinline__ void load(const x265amd_me_job *p)
+    {
+        static_assert(sizeof(x265amd_me_job) == 48 && X265AMD_MAX_MVC == 4, "job layout");
+        const uint32_t *q = (const uint32_t*)p;
+        uint32_t d[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            d[i] = q[i];
+        auto lo = [](uint32_t v) { return (int)(int16_t)(v & 0xffff); };
+        auto hi = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
+        pu_x = (int)d[0]; pu_y = (int)d[1];
+        w = lo(d[2]); h = hi(d[2]);
+        mvmin_x = lo(d[3]); mvmin_y = hi(d[3]);
+        mvmax_x = lo(d[4]); mvmax_y = hi(d[4]);
+        qmvp_x = lo(d[5]); qmvp_y = hi(d[5]);
+        merange = lo(d[6]); method = (d[6] >> 16) & 0xff; subme = d[6] >> 24;
+        qp = d[7] & 0xff; numc = (d[7] >> 8) & 0xff; ref_idx = (d[7] >> 16) & 0xff; icost = d[7] >> 24;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            mvc[i][0] = lo(d[8 + i]);
+            mvc[i][1] = hi(d[8 + i]);
+        }
+    }
+};
+
+template <class L>
 struct Search
 {
-    Wave<PIX> &W;
-    const x265amd_me_job &j;
+    Wave<L> &W;
+    const JobRegs &j;
     int bmx, bmy, bcost;
 
-    __device__ Search(Wave<PIX> &w_, const x265amd_me_job &j_) : W(w_), j(j_) {}
+    __device__ __forceinline__ Search(Wave<L> &w_, const JobRegs &j_) : W(w_), j(j_) {}
 
     __device__ __forceinline__ bool in_range(int x, int y) const   // MV::checkRange, common/mv.h:96-99
     {
@@ -60,26 +95,21 @@ struct Search
         return false;
     }
 
-    __device__ __forceinline__ int mvcost_fpel(int mx, int my) const
-    {
-        return W.mvcost(XA_S16(XA_S16(mx) << 2), XA_S16(XA_S16(my) << 2));
-    }
-
     // COST_MV (motion.cpp:173-179)
-    __device__ void try_mv(int mx, int my)
+    __device__ __forceinline__ void try_mv(int mx, int my)
     {
         take(W.cost_fpel(mx, my), mx, my);
     }
 
     // N candidates measured at (sx,sy)[k], labelled and priced as (lx,ly)[k], taken in order
     template <int N>
-    __device__ int try_points(const int *sx, const int *sy, const int *lx, const int *ly)
+    __device__ __forceinline__ int try_points(const int *sx, const int *sy, const int *lx, const int *ly)
     {
         int c[N], last = -1;
-        W.template icost_points<N>(sx, sy, c);
+        W.template eval_points<N>(sx, sy, lx, ly, c);
 #pragma unroll
         for (int k = 0; k < N; k++)
-            if (take(c[k] + mvcost_fpel(lx[k], ly[k]), lx[k], ly[k]))
+            if (take(c[k], lx[k], ly[k]))
                 last = k;
         return last;
     }
@@ -87,7 +117,7 @@ struct Search
     // N candidates (cx,cy) + d[k], all relative to one centre, in order; returns index of the last taken or -1.
     // Only the cost is updated; the caller moves bmv (pattern loops move after the whole set).
     template <int N>
-    __device__ int probe(int cx, int cy, const int8_t (*d)[2])
+    __device__ __forceinline__ int probe(int cx, int cy, const int (*d)[2])
     {
         int x[N], y[N], c[N], last = -1;
 #pragma unroll
@@ -96,14 +126,13 @@ struct Search
             x[k] = XA_S16(cx + d[k][0]);
             y[k] = XA_S16(cy + d[k][1]);
         }
-        W.template icost_points<N>(x, y, c);
+        W.template eval_points<N>(x, y, x, y, c);
 #pragma unroll
         for (int k = 0; k < N; k++)
         {
-            int cc = c[k] + mvcost_fpel(x[k], y[k]);
-            if (cc < bcost)
+            if (c[k] < bcost)
             {
-                bcost = cc;
+                bcost = c[k];
                 last = k;
             }
         }
@@ -111,7 +140,7 @@ struct Search
     }
 
     // ---------------------------------------------------------------- STAR (motion.cpp:868-1108)
-    __device__ void pt(int mx, int my, int point, int dist, int &bPointNr, int &bDistance)
+    __device__ __forceinline__ void pt(int mx, int my, int point, int dist, int &bPointNr, int &bDistance)
     {
         if (take(W.cost_fpel(mx, my), mx, my))
         {
@@ -121,20 +150,20 @@ struct Search
     }
 
     template <int N>
-    __device__ void pts(const int *x, const int *y, const int *point, const int *dist, int &bPointNr, int &bDistance)
+    __device__ __forceinline__ void pts(const int *x, const int *y, const int *point, const int *dist, int &bPointNr, int &bDistance)
     {
         int c[N];
-        W.template icost_points<N>(x, y, c);
+        W.template eval_points<N>(x, y, x, y, c);
 #pragma unroll
         for (int k = 0; k < N; k++)
-            if (take(c[k] + mvcost_fpel(x[k], y[k]), x[k], y[k]))
+            if (take(c[k], x[k], y[k]))
             {
                 bPointNr = point[k];
                 bDistance = dist[k];
             }
     }
 
-    __device__ void star_pattern(int &bPointNr, int &bDistance, int earlyExit, int merange)
+    __device__ __forceinline__ void star_pattern(int &bPointNr, int &bDistance, int earlyExit, int merange)
     {
         const int ox = bmx, oy = bmy;
         int saved = bcost, rounds = 0;
@@ -243,7 +272,7 @@ struct Search
         }
     }
 
-    __device__ void star_two_points(int bPointNr)
+    __device__ __forceinline__ void star_two_points(int bPointNr)
     {
         const int x1 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2][0]), y1 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2][1]);
         const int x2 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2 + 1][0]), y2 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2 + 1][1]);
@@ -255,7 +284,7 @@ struct Search
     // Quirk kept from the reference: inside the UMH block every x4 evaluation measures its SADs
     // relative to the search START (pix_base is computed once, motion.cpp:451) while the candidates
     // are labelled and priced relative to the CURRENT omv.
-    __device__ void umh_x4(int basex, int basey, int omx, int omy,
+    __device__ __forceinline__ void umh_x4(int basex, int basey, int omx, int omy,
                            int a0, int a1, int b0, int b1, int c0, int c1, int d0, int d1)
     {
         int sx[4] = { basex + a0, basex + b0, basex + c0, basex + d0 };
@@ -268,7 +297,7 @@ struct Search
     // CROSS (motion.cpp:251-275).  Second quirk: COST_MV(omv.x, omv.y + i) expands to
     // fref + omv.x + omv.y + i * stride, i.e. the vertical singles are measured at
     // (omv.x + omv.y, +-i) but labelled (omv.x, omv.y +- i).
-    __device__ void umh_cross(int basex, int basey, int omx, int omy, int start, int x_max, int y_max)
+    __device__ __forceinline__ void umh_cross(int basex, int basey, int omx, int omy, int start, int x_max, int y_max)
     {
         int i = XA_S16(start);
         int lim = j.mvmax_x - omx < omx - j.mvmin_x ? j.mvmax_x - omx : omx - j.mvmin_x;
@@ -301,12 +330,11 @@ struct Search
     }
 
     // ---------------------------------------------------------------- the search
-    __device__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
+    __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int job_flags, int &outx, int &outy)
     {
         int merange = j.merange;
         W.ikind = j.icost;
-        W.mvpx = j.qmvp_x;
-        W.mvpy = j.qmvp_y;
+        W.set_mvp(j.mvmin_x, j.mvmin_y, j.qmvp_x, j.qmvp_y, job_flags);      // setMVP (bitcost.h:43)
         const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
         const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);
         auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };   // MV::clipped, mv.h:88-93
@@ -322,17 +350,18 @@ struct Search
             bcost = W.cost_fpel(bmx, bmy);
         if (pmx || pmy)
         {
-            int zx = 0, zy = 0, c;
-            W.template icost_points<1>(&zx, &zy, &c);
-            c += W.mvcost(0, 0);
+            int c = W.cost_fpel(0, 0);
             if (c < bcost)
             {
                 bcost = c;
                 bmx = bmy = 0;
             }
         }
-        for (int i = 0; i < j.numc; i++)
+#pragma unroll
+        for (int i = 0; i < X265AMD_MAX_MVC; i++)
         {
+            if (i >= j.numc)
+                break;
             int mx = clipq(j.mvc[i][0], qminx, qmaxx), my = clipq(j.mvc[i][1], qminy, qmaxy);
             if ((mx || my) && !(mx == pmx && my == pmy) && !(mx == bprex && my == bprey))
             {
@@ -437,8 +466,10 @@ struct Search
                         mvd = iabs(j.qmvp_x - j.mvc[0][0]) + iabs(j.qmvp_y - j.mvc[0][1]);
                         denom++;
                     }
-                    for (int i = 0; i < j.numc - 1; i++)
-                        mvd += iabs(j.mvc[i][0] - j.mvc[i + 1][0]) + iabs(j.mvc[i][1] - j.mvc[i + 1][1]);
+#pragma unroll
+                    for (int i = 0; i < X265AMD_MAX_MVC - 1; i++)
+                        if (i < j.numc - 1)
+                            mvd += iabs(j.mvc[i][0] - j.mvc[i + 1][0]) + iabs(j.mvc[i][1] - j.mvc[i + 1][1]);
                 }
                 int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
                 int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
@@ -478,16 +509,13 @@ struct Search
                             x[k] = omx + c_hex4[q * 4 + k][0] * i;
                             y[k] = omy + c_hex4[q * 4 + k][1] * i;
                         }
-                        W.template icost_points<4>(x, y, c);
+                        W.template eval_points<4>(x, y, x, y, c, PF_NOTRUNC);
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                         {
-                            int cc = c[k] + W.cost[(int16_t)(omx * 4 + c_hex4[q * 4 + k][0] * 4 * i - W.mvpx)]
-                                          + W.cost[(int16_t)(omy * 4 + c_hex4[q * 4 + k][1] * 4 * i - W.mvpy)];
-                            cc = uni(cc);
-                            if (cc < bcost)
+                            if (c[k] < bcost)
                             {
-                                bcost = cc;
+                                bcost = c[k];
                                 best = q * 4 + k;
                             }
                         }
@@ -508,58 +536,47 @@ struct Search
 
         case X265AMD_STAR:  // motion.cpp:630-737
         {
+            // One loop holds the reference's first pattern pass (early exit after 3 rounds), its
+            // two-point / raster refinements, and the repeated passes (early exit after 32 rounds,
+            // motion.cpp:704-735), so the pattern code is instantiated once.
             int bPointNr = 0, bDistance = 0;
-            star_pattern(bPointNr, bDistance, 3, merange);
-            bool stop = false;
-            if (bDistance == 1)
+            for (bool first = true;; first = false)
             {
-                if (bPointNr)
-                {
-                    int saved = bcost;
-                    star_two_points(bPointNr);
-                    if (bcost == saved)
-                        stop = true;
-                }
-                else
-                    stop = true;
-            }
-            if (stop)
-                break;
-            if (bDistance > 5)      // raster refinement, step 5 (motion.cpp:667-701)
-            {
-                for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty = XA_S16(ty + 5))
-                    for (int tx = j.mvmin_x; tx <= j.mvmax_x; tx = XA_S16(tx + 5))
-                    {
-                        if (tx + 15 <= j.mvmax_x)
-                        {
-                            int x[4] = { tx, tx + 5, tx + 10, tx + 15 }, y[4] = { ty, ty, ty, ty }, c[4];
-                            W.template icost_points<4>(x, y, c);
-#pragma unroll
-                            for (int k = 0; k < 4; k++)
-                            {
-                                // quirk: the 4th candidate is priced with mvcost(tmv << 3) (motion.cpp:694)
-                                int sh = (k == 3) ? 3 : 2;
-                                int lx = XA_S16(x[k]);
-                                take(c[k] + W.mvcost(XA_S16(lx << sh), XA_S16(ty << sh)), lx, ty);
-                            }
-                            tx = XA_S16(tx + 15);
-                        }
-                        else
-                            try_mv(tx, ty);
-                    }
-            }
-            while (bDistance > 0)
-            {
-                bDistance = 0;
-                bPointNr = 0;
-                star_pattern(bPointNr, bDistance, 32, merange);
+                star_pattern(bPointNr, bDistance, first ? 3 : 32, merange);
                 if (bDistance == 1)
                 {
+                    // best distance 1: check the two missing outer points.  That ends the search,
+                    // except after the first pass when one of them improved the cost.
                     if (!bPointNr)
                         break;
+                    const int saved = bcost;
                     star_two_points(bPointNr);
-                    break;
+                    if (!first || bcost == saved)
+                        break;
                 }
+                if (first && bDistance > 5)      // raster refinement, step 5 (motion.cpp:667-701)
+                {
+                    for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty = XA_S16(ty + 5))
+                        for (int tx = j.mvmin_x; tx <= j.mvmax_x; tx = XA_S16(tx + 5))
+                        {
+                            if (tx + 15 <= j.mvmax_x)
+                            {
+                                int x[4] = { tx, tx + 5, tx + 10, tx + 15 }, y[4] = { ty, ty, ty, ty }, c[4];
+                                // quirk: the 4th candidate is priced with mvcost(tmv << 3) (motion.cpp:694)
+                                W.template eval_points<4>(x, y, x, y, c, 0, 3);
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    take(c[k], XA_S16(x[k]), ty);
+                                tx = XA_S16(tx + 15);
+                            }
+                            else
+                                try_mv(tx, ty);
+                        }
+                }
+                if (bDistance <= 0)
+                    break;
+                bDistance = 0;
+                bPointNr = 0;
             }
             break;
         }
@@ -575,7 +592,7 @@ struct Search
                 int fcost = 0x7fffffff, fidx = 0x7fffffff, fx = 0, fy = 0;
                 for (int s = 0; s < fb_stride; s++)
                 {
-                    int c = fb[s].cost, x = fb[s].mvx, y = fb[s].mvy;
+                    int c = uni(fb[s].cost), x = uni(fb[s].mvx), y = uni(fb[s].mvy);   // (vector loads: pin to scalar registers)
                     int idx = (y - j.mvmin_y) * nxr + (x - j.mvmin_x);
                     if (c < fcost || (c == fcost && c != 0x7fffffff && idx < fidx))
                     {
@@ -589,7 +606,7 @@ struct Search
                     bmy = fy;
                 }
                 int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-                W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;
+                W.add_evals((nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u);
             }
             else
             {
@@ -646,7 +663,7 @@ struct Search
         // sub-pel refinement (motion.cpp:786-861).  The reference's half-pel loop interpolates one
         // (w+1)xh or wx(h+1) block per direction pair; both members share the fractional phase,
         // so each candidate equals an independent subpelCompare.
-        const int8_t *wl = c_workload[j.subme];
+        const int *wl = c_workload[j.subme];
         const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
         if (wl[4])
             bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD) + W.mvcost(bmx, bmy);

@@ -64,6 +64,7 @@ struct x265amd_ctx
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
     bool   timing = false;
+    int    flags = 0;
     bool   timed_full = false, timed_any = false;
     hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 };
@@ -73,7 +74,8 @@ struct x265amd_ctx
 struct x265amd_joblist
 {
     int     n = 0, bpp = 1;
-    DevBuf  jobs, results, fb, items, item_jobs;
+    DevBuf  jobs, results, fb, items, item_jobs, idx;
+    int     cls_count[JOB_CLASSES] = { 0, 0, 0 };   // job classes of the general kernel: idx = [class 0..., class 1..., class 2...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
 };
@@ -203,6 +205,7 @@ BatchParams make_params(x265amd_ctx *c, int enc_plane, const int *ref_planes, in
         P.cost[q] = c->d_cost + (size_t)q * 65536 + 32768;
     P.enc_plane = enc_plane;
     P.n_refs = n_refs;
+    P.flags = c->flags;
     for (int i = 0; i < n_refs; i++)
         P.ref_planes[i] = ref_planes[i];
     return P;
@@ -240,15 +243,43 @@ int record_start(x265amd_ctx *c)
     return 0;
 }
 
+// idx[cls] / cnt[cls]: device index lists of the job classes (idx == NULL: every block looks at its own
+// job and the kernels of the other classes skip it)
+template <typename PIX>
+void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *d_jobs, const int *const *idx, const int *cnt,
+                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out)
+{
+    // the large PUs first: they are the long-running workgroups
+    if (cnt[2] > 0)
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 16, 1024>>), dim3(cnt[2]), dim3(1024), 0, c->stream, P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+    if (cnt[1] > 0)
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256>>), dim3(cnt[1]), dim3(256), 0, c->stream, P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+    if (cnt[0] > 0)
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64>>), dim3(cnt[0]), dim3(64), 0, c->stream, P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+}
+
 int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
+                   const int *idx_base, const int *cls_count,
                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out)
 {
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr };
+    int cnt[JOB_CLASSES] = { n, n, n };
+    if (idx_base)
+    {
+        int off = 0;
+        for (int k = 0; k < JOB_CLASSES; k++)
+        {
+            idx[k] = idx_base + off;
+            cnt[k] = cls_count[k];
+            off += cls_count[k];
+        }
+    }
     if (bpp == 1)
-        hipLaunchKernelGGL(k_search<uint8_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, fb_stride, d_out, c->d_evals);
+        launch_classes<uint8_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out);
     else
-        hipLaunchKernelGGL(k_search<uint16_t>, dim3(n), dim3(64), 0, c->stream, P, d_jobs, n, fb, fb_stride, d_out, c->d_evals);
+        launch_classes<uint16_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out);
     HIPCHK(c, hipGetLastError());
     if (c->timing)
     {
@@ -277,7 +308,7 @@ int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const
         HIPCHK(c, hipGetLastError());
         c->timed_full = true;
     }
-    return launch_general(c, P, bpp, d_jobs, n, fb, 1, d_out);
+    return launch_general(c, P, bpp, d_jobs, n, nullptr, nullptr, fb, 1, d_out);
 }
 
 // ---- exhaustive-kernel plan ------------------------------------------------------------------
@@ -417,6 +448,21 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     if (int rc = ensure(c, L->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
     HIPCHK(c, hipMemcpyAsync(L->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
 
+    {
+        std::vector<int> order;
+        for (int cls = 0; cls < JOB_CLASSES; cls++)
+        {
+            L->cls_count[cls] = 0;
+            for (int i = 0; i < n; i++)
+                if (job_class(jobs[i].w, jobs[i].h) == cls)
+                {
+                    order.push_back(i);
+                    L->cls_count[cls]++;
+                }
+        }
+        if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
+        HIPCHK(c, hipMemcpy(L->idx.p, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    }
     std::vector<PlannedItem> planned;
     if (bpp == 1)
     {
@@ -488,7 +534,7 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs };
+    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -522,6 +568,7 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
         c->timed_full = true;
     }
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
+                          (const int*)L->idx.p, L->cls_count,
                           L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
                           (x265amd_me_result*)L->results.p);
 }
@@ -589,6 +636,8 @@ int x265amd_create(int device, x265amd_ctx **out)
         delete c;
         return X265AMD_ERR_NO_DEVICE;
     }
+    if (const char *ev = getenv("X265AMD_FLAGS"))        // tuning aid, see BatchParams::flags
+        c->flags = atoi(ev);
     *out = c;
     return X265AMD_OK;
 }
