@@ -52,6 +52,21 @@ __constant__ int c_luma[4][8] = {   // HEVC luma taps, Lib/TLibCommon/TComRom.cp
     { -1, 4, -11, 40, 40, -11, 4, -1 },
     {  0, 1,  -5, 17, 58, -10, 4, -1 } };
 
+// the same taps packed for the dot-product instructions: four signed bytes per dword (taps 0-3, 4-7)
+// and two signed 16-bit values per dword (taps 0-1, 2-3, 4-5, 6-7)
+#define XA_B4(a, b, c, d) (int)(((a) & 0xffu) | (((b) & 0xffu) << 8) | (((c) & 0xffu) << 16) | (((unsigned)(d) & 0xffu) << 24))
+#define XA_H2(a, b) (int)(((a) & 0xffffu) | ((unsigned)(b) << 16))
+__constant__ int c_luma_b4[4][2] = {
+    { XA_B4(0, 0, 0, 64),   XA_B4(0, 0, 0, 0) },
+    { XA_B4(-1, 4, -10, 58), XA_B4(17, -5, 1, 0) },
+    { XA_B4(-1, 4, -11, 40), XA_B4(40, -11, 4, -1) },
+    { XA_B4(0, 1, -5, 17),  XA_B4(58, -10, 4, -1) } };
+__constant__ int c_luma_h2[4][4] = {
+    { XA_H2(0, 0),  XA_H2(0, 64),   XA_H2(0, 0),   XA_H2(0, 0) },
+    { XA_H2(-1, 4), XA_H2(-10, 58), XA_H2(17, -5), XA_H2(1, 0) },
+    { XA_H2(-1, 4), XA_H2(-11, 40), XA_H2(40, -11), XA_H2(4, -1) },
+    { XA_H2(0, 1),  XA_H2(-5, 17),  XA_H2(58, -10), XA_H2(4, -1) } };
+
 // ------------------------------------------------------------------ cross-lane helpers
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -69,17 +84,24 @@ __device__ __forceinline__ int xor4(int v) { return __builtin_amdgcn_ds_swizzle(
 __device__ __forceinline__ int xor16(int v) { return __builtin_amdgcn_ds_swizzle(v, (16 << 10) | 0x1f); }
 __device__ __forceinline__ int xor32(int v) { return __shfl_xor(v, 32); }
 
+// row_half_mirror / row_mirror: lane i of a 16-lane row reads lane (i ^ 7) / (i ^ 15) ... of the same row
 __device__ __forceinline__ int sum16(int v)   // sum over the 16-lane row, result in every lane of the row
 {
-    v += xor1(v); v += xor2(v); v += xor4(v); v += xor8(v);
+    v += xor1(v); v += xor2(v);
+    v += dpp<0x141>(v);                       // row_half_mirror: the other quad of the 8-lane half
+    v += dpp<0x140>(v);                       // row_mirror: the other half of the row
+    return v;
+}
+__device__ __forceinline__ int wave_sum_last(int v)  // sum over the wave; valid in lane 63 only
+{
+    v = sum16(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ int wave_sum(int v)  // sum over the wave, returned wave-uniform
 {
-    v = sum16(v);
-    v += xor16(v);
-    v += xor32(v);
-    return __builtin_amdgcn_readfirstlane(v);
+    return __builtin_amdgcn_readlane(wave_sum_last(v), 63);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -177,18 +199,22 @@ constexpr int CS_LEN = 640;         // entries per MV-cost slice kept in LDS (co
 constexpr int WIN_MARGIN = 8;       // pixels of search excursion the LDS reference window keeps around a staging centre
 constexpr int WIN_LOCAL = 6;        // a point set no wider than this re-centres the window; wider ones read the plane
 
-enum   // JobState::flags
+enum   // job flags (BatchParams::flags, tuning aids)
 {
-    JF_NO_WINDOW = 1,               // never stage a reference window (plain block costs; tuning aid)
-    JF_NO_SLICES = 2                // read MV costs from the global table only (tuning aid)
+    JF_NO_WINDOW = 1,               // never stage a reference window
+    JF_NO_SLICES = 2                // read MV costs from the global table only
 };
-enum   // sad_pts pricing flags
+enum   // per-call flags of the pixel functions
 {
-    PF_NOTRUNC = 1                  // do not truncate the sum of the two MV-cost entries to 16 bits
+    CF_WINDOW  = 1,                 // candidate offsets address the LDS window (bytes); else the plane (pixels)
+    CF_NOTRUNC = 2,                 // do not truncate the sum of the two MV-cost entries to 16 bits
+    CF_PAR     = 4,                 // parity of the (first) cross-wave reduction slot to use
+    CF_NOMV    = 8                  // do not add MV costs
 };
 
-// Job scalars.  Every wave of the job keeps its own copy (all copies always hold the same values,
-// because all waves run the same uniform control flow): no wave ever reads what another wrote.
+// Job scalars the out-of-line pixel functions read.  Every wave of the job keeps its own copy (all
+// copies hold the same values, because all waves run the same uniform control flow): no wave ever
+// reads what another wrote.
 struct JobState
 {
     uint64_t refbase;               // address of the reference pixel under the PU origin (encoder/motion.cpp:288)
@@ -198,12 +224,10 @@ struct JobState
     int32_t  w, h, G, T;            // PU size, 4-pixel groups, passes over the job's lanes
     int32_t  mvpx, mvpy;            // q-pel predictor the MV costs are relative to
     int32_t  cs_lo[2];              // MVD of entry 0 of the x / y cost slice
-    int32_t  flags, par;            // JF_*, parity of the next cross-wave reduction slot
-    int32_t  wx0, wy0, ww, wh;      // reference window: origin relative to the PU origin, size (pixels)
-    int32_t  wpitch, wvalid;        // window pitch in bytes; 0 while nothing is staged
-    uint32_t evals, pad;
-    int32_t  pts[8];                // candidates of the next sad_pts call: (y << 16) | (x & 0xffff), full-pel
-    int32_t  lbl[8];                // their labels for MV pricing:        (y << 16) | (x & 0xffff), q-pel
+    int32_t  wx0, wy0, ww, wh;      // reference window as last staged: origin relative to the PU origin, size (pixels)
+    int32_t  wpitch, pad;           // its pitch in bytes
+    int32_t  pts[8];                // candidates of the next eval call: offset of the block origin (window bytes / plane pixels)
+    int32_t  lbl[8];                // their labels for MV pricing: (y << 16) | (x & 0xffff), q-pel
 };
 
 // LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64)
@@ -218,7 +242,7 @@ struct JobLds
     uint32_t fenc[MAXG * DW];                   // encoder pixels of group g (cached PU, encoder/motion.cpp:104-119)
     uint16_t gxy[MAXG];                         // (y << 8) | x of group g inside the PU
     int16_t  imm[MAXG * 4 + 7 * 64];            // horizontally filtered rows -3..h+3 of an HV candidate (stride w)
-    int      red[2][NW][8];                     // cross-wave partial sums: [parity][wave][value]
+    int      red[2][8][NW];                     // cross-wave partial sums: [parity][value][wave]
     uint32_t cs[2][CS_LEN / 2];                 // MV-cost slices (uint16 entries): cost[lo_x + i], cost[lo_y + i]
     uint32_t win[WIN_BYTES / 4 + 4];            // reference window
     JobState st[NW];
@@ -226,17 +250,23 @@ struct JobLds
 
 struct Res8 { int c[8]; };
 
-// Device code of one job class.  All entry points take the job's LDS offset.
+// Device code of one job class.  All entry points take the job's LDS offset.  Scalar arguments
+// arrive in vector registers (the calling convention has no scalar arguments) but hold the same
+// value in every lane; values that steer control flow are moved to scalar registers with uni().
 template <class L>
 struct Dev
 {
     typedef typename L::PIX PIX;
-    static constexpr int NW = L::NW, NT = L::NT, DW = L::DW;
+    static constexpr int NW = L::NW, NT = L::NT, DW = L::DW, PB = (int)sizeof(PIX);
     typedef XA_LDS L *LP;
     typedef XA_LDS JobState *SP;
 
     static __device__ __forceinline__ LP lds(uint32_t base) { return (LP)(uintptr_t)base; }
     static __device__ __forceinline__ int wave_id() { return NW > 1 ? uni((int)(threadIdx.x >> 6)) : 0; }
+    static __device__ __forceinline__ uint64_t uni64(uint64_t v)
+    {
+        return ((uint64_t)(uint32_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v);
+    }
 
     static __device__ __forceinline__ void bsync()
     {
@@ -250,88 +280,105 @@ struct Dev
         }
     }
 
-    // uniform snapshot of the job scalars a pixel function works with
+    // what every pixel function starts from
     struct View
     {
         LP  l;
         SP  s;
-        int tid, lane, wv;
-        int w, h, G, T, stride, depth, gLo, gHi, flags, par;
-        int wx0, wy0, ww, wh, wpitch, wvalid;
-        const PIX *refbase;
+        int tid, lane, wv, G, T;
 
         __device__ __forceinline__ View(uint32_t base)
         {
-            l = lds(base);
+            l = lds((uint32_t)uni((int)base));
             tid = (int)threadIdx.x;
             lane = tid & 63;
             wv = wave_id();
             s = &l->st[wv];
-            refbase = (const PIX*)(((uint64_t)(uint32_t)uni((int)(s->refbase >> 32)) << 32) | (uint32_t)uni((int)s->refbase));
-            gLo = uni(s->gLo); gHi = uni(s->gHi);
-            stride = uni(s->stride); depth = uni(s->depth);
-            w = uni(s->w); h = uni(s->h); G = uni(s->G); T = uni(s->T);
-            flags = uni(s->flags); par = uni(s->par);
-            load_window();
-        }
-        __device__ __forceinline__ void load_window()
-        {
-            wx0 = uni(s->wx0); wy0 = uni(s->wy0); ww = uni(s->ww); wh = uni(s->wh);
-            wpitch = uni(s->wpitch); wvalid = uni(s->wvalid);
-        }
-        // does the window hold every pixel (with the 8-tap apron) of blocks with origins in the box?
-        __device__ __forceinline__ bool covers(int minx, int miny, int maxx, int maxy) const
-        {
-            return wvalid && minx - 3 >= wx0 && maxx + w + 5 <= wx0 + ww && miny - 3 >= wy0 && maxy + h + 4 <= wy0 + wh;
+            G = uni(s->G);
+            T = uni(s->T);
         }
 
-        // sum N per-lane values over all lanes of the job; results uniform and equal in every wave
+        // Sum N per-lane values over all lanes of the job; results uniform and equal in every wave.
+        // One barrier per reduction: consecutive reductions alternate between two slots (`par`).
         template <int N>
-        __device__ __forceinline__ void job_sum(int *v)
+        __device__ __forceinline__ void job_sum(int *v, int par)
         {
-#pragma unroll
-            for (int k = 0; k < N; k++)
-                v[k] = wave_sum(v[k]);
-            if (NW > 1)
+            if (NW == 1)
             {
-                if (lane == 0)
-                {
-#pragma unroll
-                    for (int k = 0; k < N; k++)
-                        l->red[par][wv][k] = v[k];
-                }
-                __syncthreads();
 #pragma unroll
                 for (int k = 0; k < N; k++)
-                {
-                    int t = (lane < NW) ? l->red[par][lane][k] : 0;
-                    if (NW > 8)  t += xor8(t);
-                    if (NW > 4)  t += xor4(t);
-                    if (NW > 2)  t += xor2(t);
-                    t += xor1(t);
-                    v[k] = uni(t);
-                }
-                par ^= 1;     // the next reduction uses the other slot: one barrier per reduction suffices
-                s->par = par;
+                    v[k] = wave_sum(v[k]);
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                v[k] = wave_sum_last(v[k]);
+            if (lane == 63)
+            {
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    l->red[par][k][wv] = v[k];
+            }
+            __syncthreads();
+            // lane k*S + i sums the partials of value k held by waves i*NW/S .. (S = lanes per value)
+            constexpr int S = NW > 8 ? 8 : NW, PER = NW / S;
+            int t = 0;
+            if (lane < 8 * S)
+            {
+                const XA_LDS int *q = &l->red[par][lane / S][(lane % S) * PER];
+#pragma unroll
+                for (int i = 0; i < PER; i++)
+                    t += q[i];
+            }
+            if (S > 1) t += xor1(t);
+            if (S > 2) t += xor2(t);
+            if (S > 4) t += dpp<0x141>(t);
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                v[k] = __builtin_amdgcn_readlane(t, k * S);
+        }
+    };
+
+    // ---- pixel fetch.  `off` addresses 4 (12) consecutive pixels: a byte offset into the LDS window
+    // (LW) or a pixel offset relative to refbase, clamped into the allocation.
+    struct Src
+    {
+        const XA_LDS uint32_t *win;
+        const PIX *refbase;
+        int gLo, gHi;
+
+        __device__ __forceinline__ Src(const View &v, bool lw)
+        {
+            win = v.l->win;
+            refbase = nullptr;
+            gLo = gHi = 0;
+            if (!lw)
+            {
+                // (same value in every lane, but only ever used in per-lane address arithmetic)
+                refbase = (const PIX*)v.s->refbase;
+                gLo = v.s->gLo;
+                gHi = v.s->gHi;
             }
         }
-
-        // ---- pixel fetch.  (px,py) is relative to the PU origin.
+        __device__ __forceinline__ int clamp_off(int o, int len) const
+        {
+            o = o < gLo ? gLo : o;
+            return o > gHi - len ? gHi - len : o;
+        }
         // 4 pixels as packed dwords: u8 -> r[0]; u16 -> r[0], r[1]
         template <bool LW>
-        __device__ __forceinline__ void rd4_packed(int px, int py, uint32_t *r) const
+        __device__ __forceinline__ void rd4_packed(int off, uint32_t *r) const
         {
             if (LW)
             {
-                const int a = (py - wy0) * wpitch + (px - wx0) * (int)sizeof(PIX);
-                const XA_LDS uint32_t *d = l->win + (a >> 2);
-                r[0] = __builtin_amdgcn_alignbyte(d[1], d[0], a & 3);
+                const XA_LDS uint32_t *d = win + (off >> 2);
+                r[0] = __builtin_amdgcn_alignbyte(d[1], d[0], off);
                 if (DW == 2)
-                    r[1] = __builtin_amdgcn_alignbyte(d[2], d[1], a & 3);
+                    r[1] = __builtin_amdgcn_alignbyte(d[2], d[1], off);
             }
             else
             {
-                const PIX *q = refbase + clamp_off(py * stride + px, 4);
+                const PIX *q = refbase + clamp_off(off, 4);
                 if (DW == 1)
                     r[0] = ld_u32(q);
                 else
@@ -342,184 +389,144 @@ struct Dev
                 }
             }
         }
-        static __device__ __forceinline__ P4 unpack4(const uint32_t *d)
-        {
-            P4 r;
-            if (DW == 1)
-            {
-                r.v[0] = d[0] & 0xff; r.v[1] = (d[0] >> 8) & 0xff; r.v[2] = (d[0] >> 16) & 0xff; r.v[3] = d[0] >> 24;
-            }
-            else
-            {
-                r.v[0] = d[0] & 0xffff; r.v[1] = d[0] >> 16; r.v[2] = d[1] & 0xffff; r.v[3] = d[1] >> 16;
-            }
-            return r;
-        }
+        // 12 pixels as packed dwords: u8 -> r[0..2]; u16 -> r[0..5]
         template <bool LW>
-        __device__ __forceinline__ P4 rd4(int px, int py) const
-        {
-            uint32_t d[2];
-            rd4_packed<LW>(px, py, d);
-            return unpack4(d);
-        }
-        // 12 consecutive pixels starting at (px,py)
-        template <bool LW>
-        __device__ __forceinline__ void rd12(int px, int py, int *o) const
+        __device__ __forceinline__ void rd12_packed(int off, uint32_t *r) const
         {
             if (LW)
             {
-                const int a = (py - wy0) * wpitch + (px - wx0) * (int)sizeof(PIX);
-                const XA_LDS uint32_t *d = l->win + (a >> 2);
-                const int sh = a & 3;
-                if (DW == 1)
-                {
+                const XA_LDS uint32_t *d = win + (off >> 2);
 #pragma unroll
-                    for (int i = 0; i < 3; i++)
-                    {
-                        uint32_t v = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-                        o[4 * i] = v & 0xff; o[4 * i + 1] = (v >> 8) & 0xff; o[4 * i + 2] = (v >> 16) & 0xff; o[4 * i + 3] = v >> 24;
-                    }
-                }
-                else
-                {
-#pragma unroll
-                    for (int i = 0; i < 6; i++)
-                    {
-                        uint32_t v = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-                        o[2 * i] = v & 0xffff; o[2 * i + 1] = v >> 16;
-                    }
-                }
+                for (int i = 0; i < 3 * DW; i++)
+                    r[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], off);
             }
             else
-                load12(refbase + clamp_off(py * stride + px, 12), o);
-        }
-        // per-access clamp of the direct path: a read of `len` pixels stays inside the allocation
-        __device__ __forceinline__ int clamp_off(int o, int len) const
-        {
-            o = o < gLo ? gLo : o;
-            return o > gHi - len ? gHi - len : o;
-        }
-
-        __device__ __forceinline__ P4 fenc4(int g) const
-        {
-            uint32_t d[2];
-            d[0] = l->fenc[DW * g];
-            if (DW == 2)
-                d[1] = l->fenc[DW * g + 1];
-            return unpack4(d);
-        }
-
-        // ---- prediction fetch
-        // 4 prediction pixels of the group at (gx,gy) inside a candidate block whose integer origin is
-        // (cx,cy), for interpolation mode `mode` / phase (xf,yf); filters follow common/ipfilter.cpp
-        // with hr = 14 - depth.  PRED_HV reads the horizontally filtered intermediate from LDS (see
-        // stage_hv).  `mode` is uniform: the switch is a scalar branch.
-        template <bool LW>
-        __device__ __forceinline__ P4 pred4(int mode, int cx, int cy, int gv, int xf, int yf) const
-        {
-            const int gx = gv & 0xff, gy = gv >> 8;
-            if (mode == PRED_INT)
-                return rd4<LW>(cx + gx, cy + gy);
-            const int hr = 14 - depth;
-            const int maxval = (1 << depth) - 1;
-            P4 r;
-            if (mode == PRED_H)        // filterHorizontal_p_p, ipfilter.cpp:91-139
             {
-                int px[12];
-                rd12<LW>(cx + gx - 3, cy + gy, px);
-                const int offset = 1 << (hr - 1);
+                const PIX *q = refbase + clamp_off(off, 12);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    int sum = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        sum += px[i + k] * c_luma[xf][k];
-                    int val = (int)(int16_t)(sum + offset) >> hr;
-                    val = (int16_t)val;
-                    val = val < 0 ? 0 : val;
-                    r.v[i] = val > maxval ? maxval : val;
-                }
-                return r;
+                for (int i = 0; i < 3 * DW; i++)
+                    r[i] = ld_u32((const uint8_t*)q + 4 * i);
             }
-            if (mode == PRED_V)        // filterVertical_p_p, ipfilter.cpp:354-425
-            {
-                int sum[4] = { 0, 0, 0, 0 };
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                {
-                    P4 row = rd4<LW>(cx + gx, cy + gy + k - 3);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        sum[i] += row.v[i] * c_luma[yf][k];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    int val = (int16_t)((sum[i] + 32) >> 6);
-                    val = val < 0 ? 0 : val;
-                    r.v[i] = val > maxval ? maxval : val;
-                }
-                return r;
-            }
-            // PRED_HV, second half: filterVertical_s_p (ipfilter.cpp:38-89) over the LDS intermediate,
-            // whose row k holds picture row (k - 3) of the candidate block
-            {
-                const int sh3 = 6 + hr;
-                const int off3 = (1 << (sh3 - 1)) + (8192 << 6);
-                const XA_LDS int16_t *m = l->imm + gy * w + gx;
-                int sum[4] = { 0, 0, 0, 0 };
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                {
-                    const uint64_t d = *(const XA_LDS uint64_t*)(m + k * w);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        sum[i] += (int)(int16_t)(d >> (16 * i)) * c_luma[yf][k];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    int val = (int16_t)((sum[i] + off3) >> sh3);
-                    val = val < 0 ? 0 : val;
-                    r.v[i] = val > maxval ? maxval : val;
-                }
-                return r;
-            }
-        }
-
-        // PRED_HV, first half: filterHorizontal_p_s (ipfilter.cpp:265-309) of rows -3 .. h+3 of the
-        // candidate block at (cx,cy), shared by all lanes through LDS (as the reference shares
-        // immedVal, encoder/motion.cpp:1158-1161)
-        template <bool LW>
-        __device__ __forceinline__ void stage_hv(int cx, int cy, int xf) const
-        {
-            const int hr = 14 - depth;
-            const int sh2 = 6 - hr;
-            const int off2 = -8192 * (1 << sh2);
-            const int ngx = w >> 2;
-            const int n = (h + 7) * ngx;
-            for (int idx = tid; idx < n; idx += NT)
-            {
-                int row = idx / ngx, col = (idx - row * ngx) * 4;
-                int px[12];
-                rd12<LW>(cx + col - 3, cy + row - 3, px);
-                uint64_t packed = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    int sm = 0;
-#pragma unroll
-                    for (int t = 0; t < 8; t++)
-                        sm += px[i + t] * c_luma[xf][t];
-                    int hv = (int16_t)((int)(int16_t)(sm + off2) >> sh2);
-                    packed |= (uint64_t)(uint16_t)hv << (16 * i);
-                }
-                *(XA_LDS uint64_t*)(l->imm + row * w + col) = packed;
-            }
-            bsync();
         }
     };
+
+    static __device__ __forceinline__ P4 unpack4(const uint32_t *d)
+    {
+        P4 r;
+        if (DW == 1)
+        {
+            r.v[0] = d[0] & 0xff; r.v[1] = (d[0] >> 8) & 0xff; r.v[2] = (d[0] >> 16) & 0xff; r.v[3] = d[0] >> 24;
+        }
+        else
+        {
+            r.v[0] = d[0] & 0xffff; r.v[1] = d[0] >> 16; r.v[2] = d[1] & 0xffff; r.v[3] = d[1] >> 16;
+        }
+        return r;
+    }
+
+    // 8-tap filter of 4 adjacent outputs over 12 packed pixels: out[i] = sum_k c[k] * px[i + k].
+    // The taps come packed for the dot-product instructions: 8-bit pixels use two 4-way signed byte
+    // dots per output on pixels biased by -128 (the bias, 128 * sum(c) = 8192, is added back);
+    // 16-bit pixels use four 2-way 16-bit dots.
+    struct Taps8                // 8-bit pixels: c0..c3, c4..c7 as signed bytes
+    {
+        int lo, hi;
+        __device__ __forceinline__ Taps8(int f) : lo(c_luma_b4[f][0]), hi(c_luma_b4[f][1]) {}
+    };
+    struct Taps16               // 16-bit values: (c0,c1) (c2,c3) (c4,c5) (c6,c7) as signed 16-bit pairs
+    {
+        int p[4];
+        __device__ __forceinline__ Taps16(int f)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                p[i] = c_luma_h2[f][i];
+        }
+    };
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ int dot2(uint32_t a, int b, int acc)
+    {
+        short2v x, y;
+        __builtin_memcpy(&x, &a, 4);
+        __builtin_memcpy(&y, &b, 4);
+        return __builtin_amdgcn_sdot2(x, y, acc, false);
+    }
+    static __device__ __forceinline__ void filt8x4(const uint32_t *r, int f, int *out)
+    {
+        if (DW == 1)
+        {
+            const Taps8 t(f);
+            const uint32_t b0 = r[0] ^ 0x80808080u, b1 = r[1] ^ 0x80808080u, b2 = r[2] ^ 0x80808080u;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const uint32_t a = i ? __builtin_amdgcn_alignbyte(b1, b0, i) : b0;
+                const uint32_t b = i ? __builtin_amdgcn_alignbyte(b2, b1, i) : b1;
+                int sm = __builtin_amdgcn_sdot4((int)a, t.lo, 8192, false);
+                out[i] = __builtin_amdgcn_sdot4((int)b, t.hi, sm, false);
+            }
+        }
+        else
+        {
+            const Taps16 t(f);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                // pixels i .. i+7 start at 16-bit element i: dword i/2, odd i straddles dwords
+                int sm = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int e = i + 2 * k;
+                    const uint32_t pr = (e & 1) ? __builtin_amdgcn_alignbyte(r[e / 2 + 1], r[e / 2], 2) : r[e / 2];
+                    sm = dot2(pr, t.p[k], sm);
+                }
+                out[i] = sm;
+            }
+        }
+    }
+
+    // two rows (a above b) of 4 packed 16-bit values each, times the tap pair (c[k], c[k+1]), added per column
+    static __device__ __forceinline__ void vpair16(const uint32_t *a, const uint32_t *b, int taps, int *sum)
+    {
+        sum[0] = dot2(__builtin_amdgcn_perm(b[0], a[0], 0x05040100), taps, sum[0]);
+        sum[1] = dot2(__builtin_amdgcn_perm(b[0], a[0], 0x07060302), taps, sum[1]);
+        sum[2] = dot2(__builtin_amdgcn_perm(b[1], a[1], 0x05040100), taps, sum[2]);
+        sum[3] = dot2(__builtin_amdgcn_perm(b[1], a[1], 0x07060302), taps, sum[3]);
+    }
+    // vertical 8-tap over 8 rows of 4 packed pixels: sum[i] = sum_k c[k] * row_k[i]
+    static __device__ __forceinline__ void vfilt8x4(const uint32_t (*rw)[2], int f, int *sum)
+    {
+        if (DW == 1)
+        {
+            const Taps8 t(f);
+            // byte transposes turn 4 rows x 4 columns into one dword per column, then two 4-way dots
+            uint32_t col[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+            {
+                const uint32_t r0 = rw[4 * hf][0] ^ 0x80808080u, r1 = rw[4 * hf + 1][0] ^ 0x80808080u;
+                const uint32_t r2 = rw[4 * hf + 2][0] ^ 0x80808080u, r3 = rw[4 * hf + 3][0] ^ 0x80808080u;
+                const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400), t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602);
+                const uint32_t u0 = __builtin_amdgcn_perm(r3, r2, 0x05010400), u1 = __builtin_amdgcn_perm(r3, r2, 0x07030602);
+                col[hf][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100); col[hf][1] = __builtin_amdgcn_perm(u0, t0, 0x07060302);
+                col[hf][2] = __builtin_amdgcn_perm(u1, t1, 0x05040100); col[hf][3] = __builtin_amdgcn_perm(u1, t1, 0x07060302);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sum[i] = __builtin_amdgcn_sdot4((int)col[1][i], t.hi, __builtin_amdgcn_sdot4((int)col[0][i], t.lo, 8192, false), false);
+        }
+        else
+        {
+            const Taps16 t(f);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sum[i] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2)
+                vpair16(rw[k], rw[k + 1], t.p[k / 2], sum);
+        }
+    }
 
     // ------------------------------------------------------------------ Hadamard partials
 
@@ -528,14 +535,13 @@ struct Dev
     {
         int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
         int v[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+        const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1;
         int s = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            int p = xor1(v[i]);
-            int t = (lane & 1) ? p - v[i] : v[i] + p;
-            p = xor2(t);
-            t = (lane & 2) ? p - t : t + p;
+            int t = v[i] * s1 + xor1(v[i]);          // lanes ^1: rows r, r^1  ->  sum / difference
+            t = t * s2 + xor2(t);                    // lanes ^2
             s += t < 0 ? -t : t;
         }
         return s;
@@ -546,15 +552,16 @@ struct Dev
     {
         int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
         int v[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+        const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1, s4 = (lane & 4) ? -1 : 1, s8 = (lane & 8) ? -1 : 1;
         int s = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            int t = v[i], p;
-            p = xor4(t); t = (lane & 4) ? p - t : t + p;    // horizontal: the two 4-pixel halves
-            p = xor1(t); t = (lane & 1) ? p - t : t + p;    // vertical: rows ^1, ^2, ^4
-            p = xor2(t); t = (lane & 2) ? p - t : t + p;
-            p = xor8(t); t = (lane & 8) ? p - t : t + p;
+            int t = v[i];
+            t = t * s4 + xor4(t);                    // horizontal: the two 4-pixel halves
+            t = t * s1 + xor1(t);                    // vertical: rows ^1, ^2, ^4
+            t = t * s2 + xor2(t);
+            t = t * s8 + xor8(t);
             s += t < 0 ? -t : t;
         }
         return s;
@@ -562,18 +569,19 @@ struct Dev
 
     // ------------------------------------------------------------------ out-of-line pixel functions
     // (Everything with per-lane control flow lives in these functions: the kernel body itself then
-    // has only uniform branches and compiles to scalar code.)
+    // has only uniform branches and compiles to scalar code.  All of them are leaves, so none needs
+    // a stack frame.)
 
     // cache the PU (encoder/motion.cpp:104-119): fill fenc / gxy from the encoder plane
     static __device__ __noinline__ void fill_pu(uint32_t base, uint64_t enc_addr, int enc_stride_)
     {
         View v(base);
-        const int enc_stride = uni(enc_stride_);
-        const PIX *e = (const PIX*)(((uint64_t)(uint32_t)uni((int)(enc_addr >> 32)) << 32) | (uint32_t)uni((int)enc_addr));
+        const int enc_stride = uni(enc_stride_), w = uni(v.s->w), h = uni(v.s->h);
+        const PIX *e = (const PIX*)uni64(enc_addr);
         for (int g = v.tid; g < v.G; g += NT)
         {
             int x, y;
-            group_xy(g, v.w, v.h, x, y);
+            group_xy(g, w, h, x, y);
             v.l->gxy[g] = (uint16_t)((y << 8) | x);
             const PIX *p = e + (int64_t)y * enc_stride + x;
             if (DW == 1)
@@ -592,7 +600,7 @@ struct Dev
     static __device__ __noinline__ void stage_slices(uint32_t base)
     {
         View v(base);
-        const uint16_t *cost = (const uint16_t*)(((uint64_t)(uint32_t)uni((int)(v.s->cost >> 32)) << 32) | (uint32_t)uni((int)v.s->cost));
+        const uint16_t *cost = (const uint16_t*)uni64(v.s->cost);
         const int lo[2] = { uni(v.s->cs_lo[0]), uni(v.s->cs_lo[1]) };
         for (int i = v.tid; i < CS_LEN; i += NT)
         {
@@ -605,65 +613,63 @@ struct Dev
     }
 
     // one lane publishes the job's result and evaluation count
-    static __device__ __noinline__ void publish(uint32_t base, x265amd_me_result *out, int mvx, int mvy, int cost,
-                                                unsigned long long *evals)
+    static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost,
+                                                unsigned long long *evals, unsigned n_evals)
     {
-        View v(base);
-        if (v.tid == 0)
+        if (threadIdx.x == 0)
         {
             x265amd_me_result r;
             r.mvx = (int16_t)mvx;
             r.mvy = (int16_t)mvy;
             r.cost = cost;
             *out = r;
-            atomicAdd(evals, (unsigned long long)v.s->evals);
+            atomicAdd(evals, (unsigned long long)n_evals);
         }
     }
 
-    // (Re)stage the reference window so that it covers every block (with the 8-tap apron) whose
-    // origin lies in [minx,maxx] x [miny,maxy], with as much of WIN_MARGIN around as fits.
-    // Returns 0 if even margin 0 does not fit; the caller then reads the plane directly.
-    static __device__ __noinline__ int stage_window(uint32_t base, int minx_, int miny_, int maxx_, int maxy_)
+    // (Re)stage the LDS reference window so that it holds every block (with the 8-tap apron) whose
+    // origin lies in [minx,maxx] x [miny,maxy], with as much of WIN_MARGIN around as fits; the new
+    // geometry goes to JobState.  Returns 0 (nothing changed) if even margin 0 does not fit.
+    // (The previous window's readers are all past their reduction barrier.)
+    static __device__ __noinline__ int restage(uint32_t base, int minx_, int miny_, int maxx_, int maxy_)
     {
-        const int minx = uni(minx_), miny = uni(miny_), maxx = uni(maxx_), maxy = uni(maxy_);
         View v(base);
-        const int nw = maxx - minx + v.w + 8, nh = maxy - miny + v.h + 7;
+        const int minx = uni(minx_), miny = uni(miny_), maxx = uni(maxx_), maxy = uni(maxy_);
+        const int nw = maxx - minx + uni(v.s->w) + 8, nh = maxy - miny + uni(v.s->h) + 7;
+        auto bytes = [&](int mm) { return ((((nw + 2 * mm) * PB + 3) & ~3) + 4) * (nh + 2 * mm); };
         int m = WIN_MARGIN;
-        auto bytes = [&](int mm) { return ((((nw + 2 * mm) * (int)sizeof(PIX) + 3) & ~3) + 4) * (nh + 2 * mm); };
         while (m > 0 && bytes(m) > L::WIN_BYTES)
             m--;
         if (bytes(m) > L::WIN_BYTES)
             return 0;
         const int wx0 = minx - 3 - m, wy0 = miny - 3 - m, ww = nw + 2 * m, wh = nh + 2 * m;
-        const int wpitch = (((ww * (int)sizeof(PIX)) + 3) & ~3) + 4;
-        // the previous window's readers are all past their reduction barrier, except (NW > 1) readers
-        // of a function that ended without one; a barrier here covers those
-        if (NW > 1)
-            __syncthreads();
-        const int pdw = wpitch >> 2, n = pdw * wh;
+        const int wpitch = ((ww * PB + 3) & ~3) + 4, pdw = wpitch >> 2;
+        v.s->wx0 = wx0; v.s->wy0 = wy0; v.s->ww = ww; v.s->wh = wh; v.s->wpitch = wpitch;
+        const int stride = uni(v.s->stride), gLo = uni(v.s->gLo), gHi = uni(v.s->gHi);
+        const PIX *refbase = (const PIX*)uni64(v.s->refbase);
+        const int n = pdw * wh;
         for (int i = v.tid; i < n; i += NT)
         {
             int r = i / pdw, c = i - r * pdw;
-            int o = (wy0 + r) * v.stride + wx0 + c * (4 / (int)sizeof(PIX));
-            o = o < v.gLo ? v.gLo : o;
-            o = o > v.gHi - 4 ? v.gHi - 4 : o;
-            v.l->win[i] = ld_u32(v.refbase + o);
+            int o = (wy0 + r) * stride + wx0 + c * (4 / PB);
+            o = o < gLo ? gLo : o;
+            o = o > gHi - 4 / PB ? gHi - 4 / PB : o;
+            v.l->win[i] = ld_u32(refbase + o);
         }
-        v.s->wx0 = wx0; v.s->wy0 = wy0; v.s->ww = ww; v.s->wh = wh;
-        v.s->wpitch = wpitch; v.s->wvalid = 1;
         bsync();
         return 1;
     }
 
     template <int N, bool LW>
-    static __device__ __forceinline__ void sad_loop(const View &v, const int *p, int *acc)
+    static __device__ __forceinline__ void sad_loop(const View &v, const Src &src, int pitch, const int *p, int *acc)
     {
         for (int t = 0; t < v.T; t++)
         {
             const int g = t * NT + v.tid;
             if (g < v.G)
             {
-                const int gv = v.l->gxy[g], gx = gv & 0xff, gy = gv >> 8;
+                const int gv = v.l->gxy[g];
+                const int lo = (gv >> 8) * pitch + (gv & 0xff) * (LW ? PB : 1);
                 uint32_t f[2];
                 f[0] = v.l->fenc[DW * g];
                 if (DW == 2)
@@ -672,7 +678,7 @@ struct Dev
                 for (int k = 0; k < N; k++)
                 {
                     uint32_t r[2];
-                    v.template rd4_packed<LW>((int)(int16_t)p[k] + gx, (p[k] >> 16) + gy, r);
+                    src.template rd4_packed<LW>(p[k] + lo, r);
                     if (DW == 1)
                         acc[k] = __builtin_amdgcn_sad_u8(f[0], r[0], acc[k]);
                     else
@@ -685,116 +691,152 @@ struct Dev
         }
     }
 
-    // SAD (common/pixel.cpp:78-142, the sad / sad_x3 / sad_x4 primitives) of the n <= 8 full-pel
-    // candidates in JobState::pts, each plus the MV cost of its label in JobState::lbl
-    // (COST_MV / COST_MV_X4, encoder/motion.cpp:173-249).  Entries k >= n of the result are undefined.
-    static __device__ __noinline__ Res8 sad_pts(uint32_t base, int n_, int pflags_)
+    // 4 prediction pixels of one group for interpolation mode `mode` / phase (xf,yf); filters follow
+    // common/ipfilter.cpp with hr = 14 - depth.  `off` addresses the group's first pixel in the
+    // candidate block; PRED_HV reads the horizontally filtered intermediate from LDS (stage_hv) at
+    // element `ioff`.  `mode` is uniform: the switch is a scalar branch.
+    template <bool LW>
+    static __device__ __forceinline__ P4 pred4(const View &v, const Src &src, int mode, int off, int pitch, int ioff, int w,
+                                               int depth, int xf, int yf)
     {
-        const int n = uni(n_), pflags = uni(pflags_);
-        View v(base);
-        int p[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            p[k] = uni(v.s->pts[k]);
-        int minx = (int16_t)p[0], maxx = minx, miny = p[0] >> 16, maxy = miny;
-#pragma unroll
-        for (int k = 1; k < 8; k++)
+        constexpr int step = LW ? PB : 1;
+        if (mode == PRED_INT)
         {
-            if (k >= n)
-                p[k] = p[0];                  // padding: re-measure candidate 0 (never reported)
-            int x = (int16_t)p[k], y = p[k] >> 16;
-            minx = x < minx ? x : minx; maxx = x > maxx ? x : maxx;
-            miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
+            uint32_t d[2];
+            src.template rd4_packed<LW>(off, d);
+            return unpack4(d);
         }
-        // MV cost of label k, computed by lane k while the SADs are in flight
-        int mv = 0;
-        if (v.lane < n)
+        const int hr = 14 - depth;
+        const int maxval = (1 << depth) - 1;
+        P4 r;
+        if (mode == PRED_H)        // filterHorizontal_p_p, ipfilter.cpp:91-139
         {
-            const int lb = v.s->lbl[v.lane];
-            const int dx = (int16_t)((int16_t)lb - v.s->mvpx), dy = (int16_t)((lb >> 16) - v.s->mvpy);
-            const uint16_t *tab = (const uint16_t*)v.s->cost;
-            const unsigned ix = (unsigned)(dx - v.s->cs_lo[0]), iy = (unsigned)(dy - v.s->cs_lo[1]);
-            const XA_LDS uint16_t *cs = (const XA_LDS uint16_t*)&v.l->cs[0][0];
-            int a = ix < (unsigned)CS_LEN ? cs[ix] : tab[dx];
-            int b = iy < (unsigned)CS_LEN ? cs[CS_LEN + iy] : tab[dy];
-            mv = (pflags & PF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
-        }
-        bool lw = false;
-        if (!(v.flags & JF_NO_WINDOW))
-        {
-            lw = v.covers(minx, miny, maxx, maxy);
-            if (!lw && maxx - minx <= WIN_LOCAL && maxy - miny <= WIN_LOCAL)
+            uint32_t px[6];
+            src.template rd12_packed<LW>(off - 3 * step, px);
+            int sum[4];
+            filt8x4(px, xf, sum);
+            const int offset = 1 << (hr - 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
             {
-                lw = stage_window(base, minx, miny, maxx, maxy) != 0;
-                v.load_window();
+                int val = (int)(int16_t)(sum[i] + offset) >> hr;
+                val = (int16_t)val;
+                val = val < 0 ? 0 : val;
+                r.v[i] = val > maxval ? maxval : val;
             }
+            return r;
         }
-        int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (n == 1)
+        if (mode == PRED_V)        // filterVertical_p_p, ipfilter.cpp:354-425
         {
-            if (lw) sad_loop<1, true>(v, p, acc);
-            else    sad_loop<1, false>(v, p, acc);
-            v.template job_sum<1>(acc);
-        }
-        else if (n <= 4)
-        {
-            if (lw) sad_loop<4, true>(v, p, acc);
-            else    sad_loop<4, false>(v, p, acc);
-            v.template job_sum<4>(acc);
-        }
-        else
-        {
-            if (lw) sad_loop<8, true>(v, p, acc);
-            else    sad_loop<8, false>(v, p, acc);
-            v.template job_sum<8>(acc);
-        }
-        v.s->evals += (uint32_t)n;
-        Res8 r;
+            uint32_t rw[8][2];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            r.c[k] = acc[k] + __builtin_amdgcn_readlane(mv, k);
-        return r;
+            for (int k = 0; k < 8; k++)
+                src.template rd4_packed<LW>(off + (k - 3) * pitch, rw[k]);
+            int sum[4];
+            vfilt8x4(rw, yf, sum);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                int val = (int16_t)((sum[i] + 32) >> 6);
+                val = val < 0 ? 0 : val;
+                r.v[i] = val > maxval ? maxval : val;
+            }
+            return r;
+        }
+        // PRED_HV, second half: filterVertical_s_p (ipfilter.cpp:38-89) over the LDS intermediate,
+        // whose row k holds picture row (k - 3) of the candidate block
+        {
+            const int sh3 = 6 + hr;
+            const int off3 = (1 << (sh3 - 1)) + (8192 << 6);
+            const XA_LDS int16_t *m = v.l->imm + ioff;
+            const Taps16 ty(yf);
+            int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int k = 0; k < 8; k += 2)
+            {
+                const uint64_t d0 = *(const XA_LDS uint64_t*)(m + k * w);
+                const uint64_t d1 = *(const XA_LDS uint64_t*)(m + (k + 1) * w);
+                const uint32_t a[2] = { (uint32_t)d0, (uint32_t)(d0 >> 32) }, b[2] = { (uint32_t)d1, (uint32_t)(d1 >> 32) };
+                vpair16(a, b, ty.p[k / 2], sum);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                int val = (int16_t)((sum[i] + off3) >> sh3);
+                val = val < 0 ? 0 : val;
+                r.v[i] = val > maxval ? maxval : val;
+            }
+            return r;
+        }
+    }
+    // PRED_HV, first half: filterHorizontal_p_s (ipfilter.cpp:265-309) of rows -3 .. h+3 of the
+    // candidate block, shared by all lanes through LDS (as the reference shares immedVal,
+    // encoder/motion.cpp:1158-1161)
+    template <bool LW>
+    static __device__ __forceinline__ void stage_hv(const View &v, const Src &src, int off, int pitch, int w, int h, int depth,
+                                                    int xf)
+    {
+        constexpr int step = LW ? PB : 1;
+        const int hr = 14 - depth;
+        const int sh2 = 6 - hr;
+        const int off2 = -8192 * (1 << sh2);
+        const int ngx = w >> 2;
+        const int n = (h + 7) * ngx;
+        for (int idx = v.tid; idx < n; idx += NT)
+        {
+            const int row = idx / ngx, col = (idx - row * ngx) * 4;
+            uint32_t px[6];
+            src.template rd12_packed<LW>(off + (row - 3) * pitch + (col - 3) * step, px);
+            int sm[4];
+            filt8x4(px, xf, sm);
+            uint32_t pk[2];
+#pragma unroll
+            for (int i = 0; i < 4; i += 2)
+            {
+                const int h0 = (int16_t)((int)(int16_t)(sm[i] + off2) >> sh2);
+                const int h1 = (int16_t)((int)(int16_t)(sm[i + 1] + off2) >> sh2);
+                pk[i / 2] = (uint32_t)(h0 & 0xffff) | ((uint32_t)h1 << 16);
+            }
+            *(XA_LDS uint64_t*)(v.l->imm + row * w + col) = (uint64_t)pk[0] | ((uint64_t)pk[1] << 32);
+        }
+        bsync();
     }
 
-    // Block cost of kind `kind` (sad / satd / sa8d_inter) of the cached PU against the candidate with
-    // integer origin (cx,cy) and fractional phase (xf,yf): subpelCompare for a full-resolution
-    // reference (encoder/motion.cpp:1140-1165) when the phase is non-zero.  One body for all kinds
-    // and interpolation modes (uniform switches) keeps the instruction footprint small.
-    static __device__ __noinline__ int cost_any(uint32_t base, int cx_, int cy_, int frac_, int kind_)
+    // Block cost of kind `kind` (sad / satd / sa8d_inter) of the cached PU against the candidate
+    // whose block origin is at `off` (window bytes if lw, else plane pixels) with fractional phase
+    // (xf,yf): subpelCompare for a full-resolution reference (encoder/motion.cpp:1140-1165) when the
+    // phase is non-zero.  One body for all kinds and interpolation modes (uniform switches) keeps
+    // the instruction footprint small.
+    static __device__ __forceinline__ int cost_body(View &v, const Src &src, bool lw, int off, int pitch, int xf, int yf,
+                                                    int kind, int par)
     {
-        const int cx = uni(cx_), cy = uni(cy_), kind = uni(kind_);
-        const int xf = uni(frac_) & 3, yf = uni(frac_) >> 2;
-        View v(base);
+        const int w = uni(v.s->w), h = uni(v.s->h), depth = v.s->depth;
         const int mode = (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
-        const bool m8 = ((v.w | v.h) & 7) == 0;
-        const bool m16 = ((v.w | v.h) & 15) == 0;
-        bool lw = false;
-        if (!(v.flags & JF_NO_WINDOW))
-        {
-            lw = v.covers(cx, cy, cx, cy);
-            if (!lw)
-            {
-                lw = stage_window(base, cx, cy, cx, cy) != 0;
-                v.load_window();
-            }
-        }
+        const bool m8 = ((w | h) & 7) == 0;
+        const bool m16 = ((w | h) & 15) == 0;
         if (mode == PRED_HV)
         {
-            if (lw) v.template stage_hv<true>(cx, cy, xf);
-            else    v.template stage_hv<false>(cx, cy, xf);
+            if (lw) stage_hv<true>(v, src, off, pitch, w, h, depth, xf);
+            else    stage_hv<false>(v, src, off, pitch, w, h, depth, xf);
         }
         // which accumulation: 0 sad, 1 4x4 Hadamard (halved at the end), 2 8x8 with 8x8 rounding, 3 8x8 with 16x16 rounding
         const int am = kind == X265AMD_SAD ? 0 : (kind == X265AMD_SATD || !m8) ? 1 : (m16 ? 3 : 2);
-        int acc[2] = { 0, 0 };      // [0] per-lane partials, [1] sums already rounded per 16x16 (lane 0 only)
+        int acc[2] = { 0, 0 };      // [0] per-lane partials, [1] sums already rounded per 16x16 (lane 63 only)
         for (int t = 0; t < v.T; t++)
         {
             const int g = t * NT + v.tid;
             int d[4] = { 0, 0, 0, 0 };
             if (g < v.G)
             {
-                const int gv = v.l->gxy[g];
-                P4 f = v.fenc4(g);
-                P4 r = lw ? v.template pred4<true>(mode, cx, cy, gv, xf, yf) : v.template pred4<false>(mode, cx, cy, gv, xf, yf);
+                const int gv = v.l->gxy[g], gx = gv & 0xff, gy = gv >> 8;
+                uint32_t fd[2];
+                fd[0] = v.l->fenc[DW * g];
+                if (DW == 2)
+                    fd[1] = v.l->fenc[DW * g + 1];
+                const P4 f = unpack4(fd);
+                const int lo = off + gy * pitch + gx * (lw ? PB : 1);
+                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, gy * w + gx, w, depth, xf, yf)
+                                : pred4<false>(v, src, mode, lo, pitch, gy * w + gx, w, depth, xf, yf);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     d[i] = f.v[i] - r.v[i];
@@ -812,8 +854,8 @@ struct Dev
                 int sm = had8_partial(d, v.lane);
                 if (am == 3)
                 {
-                    int s64 = wave_sum(sm);                                  // sa8d16: one rounding per 16x16 (= one wave pass)
-                    acc[1] += (v.lane == 0) ? ((s64 + 2) >> 2) : 0;
+                    int s64 = wave_sum_last(sm);                             // sa8d16: one rounding per 16x16 (= one wave pass)
+                    acc[1] += (v.lane == 63) ? ((s64 + 2) >> 2) : 0;
                 }
                 else
                 {
@@ -822,46 +864,143 @@ struct Dev
                 }
             }
         }
-        v.s->evals += 1;
-        v.template job_sum<2>(acc);
+        v.template job_sum<2>(acc, par);
         int tot = acc[0];
         if (am == 1)
             tot >>= 1;                                                       // every 4x4 |H| sum is even
         return tot + acc[1];
     }
+
+    // MV cost of label k (JobState::lbl), computed by lane k < n; 0 elsewhere or with CF_NOMV
+    static __device__ __forceinline__ int label_cost(const View &v, int n, int cflags)
+    {
+        int mv = 0;
+        if (!(cflags & CF_NOMV) && v.lane < n)
+        {
+            const int lb = v.s->lbl[v.lane];
+            const int dx = (int16_t)((int16_t)lb - v.s->mvpx), dy = (int16_t)((lb >> 16) - v.s->mvpy);
+            const uint16_t *tab = (const uint16_t*)v.s->cost;
+            const unsigned ix = (unsigned)(dx - v.s->cs_lo[0]), iy = (unsigned)(dy - v.s->cs_lo[1]);
+            const XA_LDS uint16_t *cs = (const XA_LDS uint16_t*)&v.l->cs[0][0];
+            int a = ix < (unsigned)CS_LEN ? cs[ix] : tab[dx];
+            int b = iy < (unsigned)CS_LEN ? cs[CS_LEN + iy] : tab[dy];
+            mv = (cflags & CF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
+        }
+        return mv;
+    }
+
+    // The two evaluation entry points: costs of the n <= 8 candidates whose block-origin offsets are
+    // in JobState::pts, each plus (unless CF_NOMV) the MV cost of its label in JobState::lbl
+    // (COST_MV / COST_MV_X4, encoder/motion.cpp:173-249).  Entries k >= n of the result are undefined.
+    //
+    // eval_sad: full-pel SADs, all candidates in one pass over the PU, like the sad / sad_x3 /
+    // sad_x4 primitives (common/pixel.cpp:78-142).
+    static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_)
+    {
+        const int n = uni(n_), cflags = uni(cflags_);
+        View v(base);
+        const bool lw = (cflags & CF_WINDOW) != 0;
+        const int pitch = lw ? v.s->wpitch : v.s->stride;
+        Src src(v, lw);
+        const int mv = label_cost(v, n, cflags);
+        const int par = (cflags & CF_PAR) ? 1 : 0;
+        int p[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            p[k] = v.s->pts[k];             // (entries >= n repeat candidate 0)
+        int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (n == 1)
+        {
+            if (lw) sad_loop<1, true>(v, src, pitch, p, acc);
+            else    sad_loop<1, false>(v, src, pitch, p, acc);
+            v.template job_sum<1>(acc, par);
+        }
+        else if (n <= 4)
+        {
+            if (lw) sad_loop<4, true>(v, src, pitch, p, acc);
+            else    sad_loop<4, false>(v, src, pitch, p, acc);
+            v.template job_sum<4>(acc, par);
+        }
+        else
+        {
+            if (lw) sad_loop<8, true>(v, src, pitch, p, acc);
+            else    sad_loop<8, false>(v, src, pitch, p, acc);
+            v.template job_sum<8>(acc, par);
+        }
+        Res8 r;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            r.c[k] = acc[k] + __builtin_amdgcn_readlane(mv, k);
+        return r;
+    }
+
+    // eval_any: any cost kind and phase (frac = xf | yf << 2, the same for all candidates), one
+    // cost_body per candidate.
+    static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_frac_)
+    {
+        const int n = uni(n_), cflags = uni(cflags_);
+        const int kind = uni(kind_frac_) & 0xff, frac = uni(kind_frac_) >> 8;
+        View v(base);
+        const bool lw = (cflags & CF_WINDOW) != 0;
+        const int pitch = lw ? v.s->wpitch : v.s->stride;
+        Src src(v, lw);
+        int res = label_cost(v, n, cflags);     // lane k collects candidate k
+        int par = (cflags & CF_PAR) ? 1 : 0;
+        for (int k = 0; k < n; k++)
+        {
+            const int off = v.s->pts[k];
+            const int c = cost_body(v, src, lw, off, pitch, frac & 3, frac >> 2, kind, par);
+            res += (v.lane == k) ? c : 0;
+            par ^= 1;
+        }
+        Res8 r;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            r.c[k] = __builtin_amdgcn_readlane(res, k);
+        return r;
+    }
 };
 
 // ------------------------------------------------------------------ caller side
 
-// What the (scalar, inlined) search logic holds of a job: the LDS offset and the few scalars it
-// needs itself.  Everything else lives in LDS (JobState).
+// What the (scalar, inlined) search logic holds of a job: the LDS offset, the PU size, the MV-cost
+// context and the geometry of the LDS reference window - all in scalar registers.
 template <class L>
 struct Wave
 {
     typedef typename L::PIX PIX;
     typedef Dev<L> D;
-    static constexpr int NW = L::NW, NT = L::NT, DW = L::DW;
+    static constexpr int NW = L::NW, NT = L::NT, DW = L::DW, PB = (int)sizeof(PIX);
 
     uint32_t base;
     typename D::LP l;
     typename D::SP s;
-    int tid, w, h, mvpx, mvpy, ikind;
+    int w, h, stride, mvpx, mvpy, ikind, jflags;
     int cs_lo[2];
     const uint16_t *cost;
+    int wx0, wy0, ww, wh, wpitch;   // reference window: origin relative to the PU origin, size (pixels), pitch (bytes)
+    bool wvalid;
+    int par;                        // parity of the next cross-wave reduction slot (CF_PAR or 0)
+    unsigned evals;
 
     // bind the PU: fill fenc / gxy / JobState.  (enc_x,enc_y) / (ref_x,ref_y): PU origin in the two planes.
-    __device__ __forceinline__ void bind(L &lds_obj, const PlaneDesc &enc, const PlaneDesc &ref, int enc_x, int enc_y, int ref_x, int ref_y,
-                         int w_, int h_, const uint16_t *cost_, int flags)
+    __device__ __forceinline__ void bind(L &lds_obj, const PlaneDesc &enc, const PlaneDesc &ref, int enc_x, int enc_y,
+                                         int ref_x, int ref_y, int w_, int h_, const uint16_t *cost_, int flags)
     {
         l = (typename D::LP)&lds_obj;
         base = (uint32_t)(uintptr_t)l;
-        tid = (int)threadIdx.x;
         s = &l->st[D::wave_id()];
         w = w_; h = h_;
+        stride = ref.stride;
         cost = cost_;
         ikind = X265AMD_SAD;
+        jflags = flags;
         mvpx = mvpy = 0;
         cs_lo[0] = cs_lo[1] = 0x7fffffff;
+        wvalid = false;
+        wx0 = wy0 = ww = wh = wpitch = 0;
+        par = 0;
+        evals = 0;
         const int G = (w * h) >> 2;
         const int64_t blockOffset = (int64_t)ref_y * ref.stride + ref_x;
         s->refbase = (uint64_t)((const PIX*)ref.origin + blockOffset);
@@ -872,15 +1011,9 @@ struct Wave
         s->w = w; s->h = h; s->G = G; s->T = (G + NT - 1) / NT;
         s->mvpx = 0; s->mvpy = 0;
         s->cs_lo[0] = s->cs_lo[1] = 0x7fffffff;
-        s->flags = flags; s->par = 0;
-        s->wx0 = s->wy0 = s->ww = s->wh = s->wpitch = s->wvalid = 0;
-        s->evals = 0;
         const PIX *e = (const PIX*)enc.origin + (int64_t)enc_y * enc.stride + enc_x;
         D::fill_pu(base, (uint64_t)e, enc.stride);
     }
-
-    __device__ __forceinline__ unsigned evals() const { return (unsigned)uni((int)s->evals); }
-    __device__ __forceinline__ void add_evals(unsigned n) { s->evals += n; }
 
     // MV cost table entry for MVD `mvd` on an axis: from the LDS slice when inside it
     __device__ __forceinline__ int cost_entry(int axis, int mvd) const
@@ -900,18 +1033,81 @@ struct Wave
 
     // setMVP (encoder/bitcost.h:43) + keep the part of the MV-cost table the search will index in
     // LDS: MVDs of q-pel MVs in [4*(mvmin-8), ...) relative to the predictor
-    __device__ __forceinline__ void set_mvp(int mvmin_x, int mvmin_y, int mvpx_, int mvpy_, int flags)
+    __device__ __forceinline__ void set_mvp(int mvmin_x, int mvmin_y, int mvpx_, int mvpy_)
     {
         mvpx = mvpx_;
         mvpy = mvpy_;
         s->mvpx = mvpx; s->mvpy = mvpy;
-        if (flags & JF_NO_SLICES)
+        if (jflags & JF_NO_SLICES)
             return;
         // even first index: the slice is copied as aligned dwords (two entries each)
         cs_lo[0] = (4 * (mvmin_x - 8) - mvpx) & ~1;
         cs_lo[1] = (4 * (mvmin_y - 8) - mvpy) & ~1;
         s->cs_lo[0] = cs_lo[0]; s->cs_lo[1] = cs_lo[1];
         D::stage_slices(base);
+    }
+
+    // ---------------------------------------------------------------- LDS reference window policy
+    // Decide where the blocks with origins in [minx,maxx] x [miny,maxy] (with the 8-tap apron) are
+    // read from: the window if it holds them; else, for a compact point set, a window re-staged
+    // around them; else the plane.  Returns CF_WINDOW or 0.
+    __device__ __forceinline__ int place(int minx, int miny, int maxx, int maxy)
+    {
+        if (jflags & JF_NO_WINDOW)
+            return 0;
+        if (wvalid && minx - 3 >= wx0 && maxx + w + 5 <= wx0 + ww && miny - 3 >= wy0 && maxy + h + 4 <= wy0 + wh)
+            return CF_WINDOW;
+        if (maxx - minx > WIN_LOCAL || maxy - miny > WIN_LOCAL)
+            return 0;
+        if (!uni(D::restage(base, minx, miny, maxx, maxy)))
+            return 0;
+        wx0 = uni(s->wx0); wy0 = uni(s->wy0); ww = uni(s->ww); wh = uni(s->wh); wpitch = uni(s->wpitch);
+        wvalid = true;
+        return CF_WINDOW;
+    }
+    // offset of the block with origin (cx,cy) in the addressing `where` selected, and that addressing's pitch
+    __device__ __forceinline__ int block_off(int where, int cx, int cy) const
+    {
+        return where ? (cy - wy0) * wpitch + (cx - wx0) * PB : cy * stride + cx;
+    }
+    // reduction slot parity for a call that performs `count` reductions
+    __device__ __forceinline__ int take_par(int count)
+    {
+        const int p = par;
+        if (NW > 1 && (count & 1))
+            par ^= CF_PAR;
+        return p;
+    }
+
+    // Costs of N candidate blocks with full-pel origins (sx,sy)[k], all of kind `kind` and phase
+    // `frac`, plus (unless CF_NOMV) the MV costs of the q-pel labels (qx,qy)[k].
+    template <int N>
+    __device__ __forceinline__ void eval_n(const int *sx, const int *sy, const int *qx, const int *qy, int kind, int frac,
+                                           int cflags, int *out)
+    {
+        int minx = sx[0], maxx = sx[0], miny = sy[0], maxy = sy[0];
+#pragma unroll
+        for (int k = 1; k < N; k++)
+        {
+            minx = sx[k] < minx ? sx[k] : minx; maxx = sx[k] > maxx ? sx[k] : maxx;
+            miny = sy[k] < miny ? sy[k] : miny; maxy = sy[k] > maxy ? sy[k] : maxy;
+        }
+        const int where = place(minx, miny, maxx, maxy);
+        constexpr int NP = N == 1 ? 1 : N <= 4 ? 4 : 8;     // candidates the SAD pass measures (padding: candidate 0)
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+        {
+            s->pts[k] = block_off(where, sx[k < N ? k : 0], sy[k < N ? k : 0]);
+            if (k < N)
+                s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
+        }
+        evals += N;
+        const bool multi = kind == X265AMD_SAD && frac == 0;
+        Res8 r = multi ? D::eval_sad(base, N, where | cflags | take_par(1))
+                       : D::eval_any(base, N, where | cflags | take_par(N), kind | (frac << 8));
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            out[k] = uni(r.c[k]);
     }
 
     // Integer-stage cost (the reference's `sad`) of N full-pel candidates measured at (sx,sy)[k],
@@ -929,29 +1125,7 @@ struct Wave
             qx[k] = (int16_t)((int16_t)lx[k] << sh);
             qy[k] = (int16_t)((int16_t)ly[k] << sh);
         }
-        if (ikind == X265AMD_SAD)
-        {
-#pragma unroll
-            for (int k = 0; k < N; k++)
-            {
-                s->pts[k] = (sy[k] << 16) | (sx[k] & 0xffff);
-                s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
-            }
-            Res8 r = D::sad_pts(base, N, pflags);
-#pragma unroll
-            for (int k = 0; k < N; k++)
-                out[k] = uni(r.c[k]);
-        }
-        else
-        {
-#pragma unroll
-            for (int k = 0; k < N; k++)
-            {
-                int c = uni(D::cost_any(base, sx[k], sy[k], 0, ikind));
-                int a = cost_entry(0, (int16_t)(qx[k] - mvpx)), b = cost_entry(1, (int16_t)(qy[k] - mvpy));
-                out[k] = c + ((pflags & PF_NOTRUNC) ? a + b : ((a + b) & 0xffff));
-            }
-        }
+        eval_n<N>(sx, sy, qx, qy, ikind, 0, pflags, out);
     }
 
     // COST_MV's value: cost at full-pel (mx,my) + mvcost(MV(mx,my) << 2)   (motion.cpp:173-179)
@@ -962,14 +1136,24 @@ struct Wave
         return c;
     }
 
-    // subpelCompare for a full-resolution reference (motion.cpp:1140-1165), no MV cost
-    __device__ __forceinline__ int subpel_cost(int qx, int qy, int kind)
+    // subpelCompare for a full-resolution reference (motion.cpp:1140-1165) at q-pel (qx,qy);
+    // with_mv: plus mvcost(MV(qx,qy))
+    __device__ __forceinline__ int subpel_cost(int qx, int qy, int kind, bool with_mv)
     {
-        return uni(D::cost_any(base, qx >> 2, qy >> 2, (qx & 3) | ((qy & 3) << 2), kind));
+        const int cx = qx >> 2, cy = qy >> 2;
+        int c;
+        eval_n<1>(&cx, &cy, &qx, &qy, kind, (qx & 3) | ((qy & 3) << 2), with_mv ? 0 : CF_NOMV, &c);
+        return c;
     }
 
     // plain block cost against the block at the reference origin
-    __device__ __forceinline__ int cost_direct(int kind) { return uni(D::cost_any(base, 0, 0, 0, kind)); }
+    __device__ __forceinline__ int cost_direct(int kind)
+    {
+        const int z = 0;
+        int c;
+        eval_n<1>(&z, &z, &z, &z, kind, 0, CF_NOMV, &c);
+        return c;
+    }
 };
 
 } // namespace xa

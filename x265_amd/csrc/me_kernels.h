@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
     Search<L> S(W, j);
     int ox, oy;
     const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(typename L::PIX))) ? fb + (size_t)id * fb_stride : nullptr;
-    int cost = S.run(f, fb_stride, P.flags, ox, oy);
-    Dev<L>::publish(W.base, out + id, ox, oy, cost, evals);
+    int cost = S.run(f, fb_stride, ox, oy);
+    Dev<L>::publish(out + id, ox, oy, cost, evals, W.evals);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) k_cost(const PlaneDesc *planes, int kind, 
     W.bind(lds, planes[p.enc_plane], planes[p.ref_plane], p.enc_x, p.enc_y, p.ref_x, p.ref_y, w, h, nullptr,
            JF_NO_WINDOW | JF_NO_SLICES);
     int c = W.cost_direct(kind);
-    if (W.tid == 0)
+    if (threadIdx.x == 0)
         out[id] = c;
 }
 

@@ -330,11 +330,11 @@ struct Search
     }
 
     // ---------------------------------------------------------------- the search
-    __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int job_flags, int &outx, int &outy)
+    __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
     {
         int merange = j.merange;
         W.ikind = j.icost;
-        W.set_mvp(j.mvmin_x, j.mvmin_y, j.qmvp_x, j.qmvp_y, job_flags);      // setMVP (bitcost.h:43)
+        W.set_mvp(j.mvmin_x, j.mvmin_y, j.qmvp_x, j.qmvp_y);      // setMVP (bitcost.h:43)
         const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
         const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);
         auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };   // MV::clipped, mv.h:88-93
@@ -342,7 +342,7 @@ struct Search
         // predictor phase (motion.cpp:302-342)
         int pmx = clipq(j.qmvp_x, qminx, qmaxx), pmy = clipq(j.qmvp_y, qminy, qmaxy);
         int bprex = pmx, bprey = pmy;
-        int bprecost = W.subpel_cost(pmx, pmy, W.ikind);          // no mvcost term (motion.cpp:305)
+        int bprecost = W.subpel_cost(pmx, pmy, W.ikind, false);          // no mvcost term (motion.cpp:305)
         bmx = XA_S16(XA_S16(pmx + 2) >> 2);
         bmy = XA_S16(XA_S16(pmy + 2) >> 2);
         bcost = bprecost;
@@ -365,7 +365,7 @@ struct Search
             int mx = clipq(j.mvc[i][0], qminx, qmaxx), my = clipq(j.mvc[i][1], qminy, qmaxy);
             if ((mx || my) && !(mx == pmx && my == pmy) && !(mx == bprex && my == bprey))
             {
-                int c = W.subpel_cost(mx, my, W.ikind) + W.mvcost(mx, my);
+                int c = W.subpel_cost(mx, my, W.ikind, true);
                 if (c < bprecost)
                 {
                     bprecost = c;
@@ -509,7 +509,7 @@ struct Search
                             x[k] = omx + c_hex4[q * 4 + k][0] * i;
                             y[k] = omy + c_hex4[q * 4 + k][1] * i;
                         }
-                        W.template eval_points<4>(x, y, x, y, c, PF_NOTRUNC);
+                        W.template eval_points<4>(x, y, x, y, c, CF_NOTRUNC);
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                         {
@@ -606,7 +606,7 @@ struct Search
                     bmy = fy;
                 }
                 int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-                W.add_evals((nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u);
+                W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;
             }
             else
             {
@@ -666,14 +666,16 @@ struct Search
         const int *wl = c_workload[j.subme];
         const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
         if (wl[4])
-            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD) + W.mvcost(bmx, bmy);
+            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
+#pragma nounroll
         for (int it = 0; it < wl[0]; it++)
         {
             int bdir = 0;
+#pragma nounroll
             for (int i = 1; i <= wl[1]; i++)
             {
                 int qx = XA_S16(bmx + c_square1[i][0] * 2), qy = XA_S16(bmy + c_square1[i][1] * 2);
-                int c = W.subpel_cost(qx, qy, hkind) + W.mvcost(qx, qy);
+                int c = W.subpel_cost(qx, qy, hkind, true);
                 if (c < bcost)
                 {
                     bcost = c;
@@ -684,14 +686,16 @@ struct Search
             bmy = XA_S16(bmy + c_square1[bdir][1] * 2);
         }
         if (!wl[4])
-            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD) + W.mvcost(bmx, bmy);
+            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
+#pragma nounroll
         for (int it = 0; it < wl[2]; it++)
         {
             int bdir = 0;
+#pragma nounroll
             for (int i = 1; i <= wl[3]; i++)
             {
                 int qx = XA_S16(bmx + c_square1[i][0]), qy = XA_S16(bmy + c_square1[i][1]);
-                int c = W.subpel_cost(qx, qy, X265AMD_SATD) + W.mvcost(qx, qy);
+                int c = W.subpel_cost(qx, qy, X265AMD_SATD, true);
                 if (c < bcost)
                 {
                     bcost = c;
