@@ -212,9 +212,8 @@ enum   // per-call flags of the pixel functions
     CF_NOMV    = 8                  // do not add MV costs
 };
 
-// Job scalars the out-of-line pixel functions read.  Every wave of the job keeps its own copy (all
-// copies hold the same values, because all waves run the same uniform control flow): no wave ever
-// reads what another wrote.
+// Job scalars the out-of-line pixel functions read.  Written by the job's leader wave only, and only
+// while the other waves wait at the command barrier (see Dev::worker).
 struct JobState
 {
     uint64_t refbase;               // address of the reference pixel under the PU origin (encoder/motion.cpp:288)
@@ -245,7 +244,8 @@ struct JobLds
     int      red[2][8][NW];                     // cross-wave partial sums: [parity][value][wave]
     uint32_t cs[2][CS_LEN / 2];                 // MV-cost slices (uint16 entries): cost[lo_x + i], cost[lo_y + i]
     uint32_t win[WIN_BYTES / 4 + 4];            // reference window
-    JobState st[NW];
+    JobState st;
+    int      cmd[8];                            // command posted by the leader wave: op, arguments (NW > 1)
 };
 
 struct Res8 { int c[8]; };
@@ -293,7 +293,7 @@ struct Dev
             tid = (int)threadIdx.x;
             lane = tid & 63;
             wv = wave_id();
-            s = &l->st[wv];
+            s = &l->st;
             G = uni(s->G);
             T = uni(s->T);
         }
@@ -320,6 +320,8 @@ struct Dev
                     l->red[par][k][wv] = v[k];
             }
             __syncthreads();
+            if (wv != 0)
+                return;                     // only the leader wave consumes results
             // lane k*S + i sums the partials of value k held by waves i*NW/S .. (S = lanes per value)
             constexpr int S = NW > 8 ? 8 : NW, PER = NW / S;
             int t = 0;
@@ -596,18 +598,20 @@ struct Dev
         bsync();
     }
 
-    // copy the slices [cs_lo, cs_lo + CS_LEN) of the MV cost table into LDS
+    // copy the slices [cs_lo, cs_lo + CS_LEN) of the MV cost table into LDS (cs_lo: multiples of 8
+    // entries, so that both sides are 16-byte aligned)
     static __device__ __noinline__ void stage_slices(uint32_t base)
     {
         View v(base);
         const uint16_t *cost = (const uint16_t*)uni64(v.s->cost);
         const int lo[2] = { uni(v.s->cs_lo[0]), uni(v.s->cs_lo[1]) };
-        for (int i = v.tid; i < CS_LEN; i += NT)
+        constexpr int PER_AXIS = CS_LEN / 8;                 // 16-byte pieces per slice
+        for (int i = v.tid; i < 2 * PER_AXIS; i += NT)
         {
-            const int axis = i >= CS_LEN / 2, k = i - axis * (CS_LEN / 2);
-            // entries past +-32767 wrap like the (int16_t) index of a direct lookup would
-            const int m0 = (int16_t)(lo[axis] + 2 * k), m1 = (int16_t)(lo[axis] + 2 * k + 1);
-            v.l->cs[axis][k] = (uint32_t)cost[m0] | ((uint32_t)cost[m1] << 16);
+            const int axis = i >= PER_AXIS, k = i - axis * PER_AXIS;
+            const uint4 d = *(const uint4*)(cost + lo[axis] + 8 * k);
+            XA_LDS uint32_t *q = &v.l->cs[axis][4 * k];
+            q[0] = d.x; q[1] = d.y; q[2] = d.z; q[3] = d.w;
         }
         bsync();
     }
@@ -641,7 +645,10 @@ struct Dev
         while (m > 0 && bytes(m) > L::WIN_BYTES)
             m--;
         if (bytes(m) > L::WIN_BYTES)
+        {
+            bsync();            // (every cooperative function passes at least one barrier: see worker())
             return 0;
+        }
         const int wx0 = minx - 3 - m, wy0 = miny - 3 - m, ww = nw + 2 * m, wh = nh + 2 * m;
         const int wpitch = ((ww * PB + 3) & ~3) + 4, pdw = wpitch >> 2;
         v.s->wx0 = wx0; v.s->wy0 = wy0; v.s->ww = ww; v.s->wh = wh; v.s->wpitch = wpitch;
@@ -959,6 +966,47 @@ struct Dev
             r.c[k] = __builtin_amdgcn_readlane(res, k);
         return r;
     }
+
+    // ---------------------------------------------------------------- leader / worker protocol (NW > 1)
+    // The search logic runs on the job's first wave only.  The other waves wait at a barrier for
+    // a command {op, arguments} in JobLds::cmd, run the same cooperative function as the leader
+    // (which contains the same barriers), and return to the barrier.  The leader posts a command
+    // only after the previous function's last barrier, i.e. when every worker has read the
+    // previous one.
+    enum { OP_EXIT = 0, OP_FILL, OP_SLICES, OP_RESTAGE, OP_SAD, OP_ANY };
+
+    static __device__ __forceinline__ void post(uint32_t base, int op, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0)
+    {
+        if (NW > 1)
+        {
+            LP l = lds(base);
+            l->cmd[0] = op; l->cmd[1] = a0; l->cmd[2] = a1; l->cmd[3] = a2; l->cmd[4] = a3;
+            __syncthreads();
+        }
+    }
+
+    static __device__ __forceinline__ void worker(uint32_t base)
+    {
+        LP l = lds(base);
+        for (;;)
+        {
+            __syncthreads();
+            const int op = uni(l->cmd[0]);
+            const int a0 = uni(l->cmd[1]), a1 = uni(l->cmd[2]), a2 = uni(l->cmd[3]), a3 = uni(l->cmd[4]);
+            if (op == OP_EXIT)
+                break;
+            if (op == OP_SAD)
+                eval_sad(base, a0, a1);
+            else if (op == OP_ANY)
+                eval_any(base, a0, a1, a2);
+            else if (op == OP_RESTAGE)
+                restage(base, a0, a1, a2, a3);
+            else if (op == OP_SLICES)
+                stage_slices(base);
+            else
+                fill_pu(base, ((uint64_t)(uint32_t)a1 << 32) | (uint32_t)a0, a2);
+        }
+    }
 };
 
 // ------------------------------------------------------------------ caller side
@@ -982,6 +1030,12 @@ struct Wave
     bool wvalid;
     int par;                        // parity of the next cross-wave reduction slot (CF_PAR or 0)
     unsigned evals;
+#ifdef XA_PROFILE                   // developer aid: shader-clock stamps at phase boundaries of the search
+    long long tstamp[8];
+    __device__ __forceinline__ void stamp(int k) { tstamp[k] = (long long)__builtin_readcyclecounter(); }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+#endif
 
     // bind the PU: fill fenc / gxy / JobState.  (enc_x,enc_y) / (ref_x,ref_y): PU origin in the two planes.
     __device__ __forceinline__ void bind(L &lds_obj, const PlaneDesc &enc, const PlaneDesc &ref, int enc_x, int enc_y,
@@ -989,7 +1043,7 @@ struct Wave
     {
         l = (typename D::LP)&lds_obj;
         base = (uint32_t)(uintptr_t)l;
-        s = &l->st[D::wave_id()];
+        s = &l->st;
         w = w_; h = h_;
         stride = ref.stride;
         cost = cost_;
@@ -1012,6 +1066,7 @@ struct Wave
         s->mvpx = 0; s->mvpy = 0;
         s->cs_lo[0] = s->cs_lo[1] = 0x7fffffff;
         const PIX *e = (const PIX*)enc.origin + (int64_t)enc_y * enc.stride + enc_x;
+        D::post(base, D::OP_FILL, (int)(uint32_t)(uint64_t)e, (int)((uint64_t)e >> 32), enc.stride);
         D::fill_pu(base, (uint64_t)e, enc.stride);
     }
 
@@ -1040,25 +1095,33 @@ struct Wave
         s->mvpx = mvpx; s->mvpy = mvpy;
         if (jflags & JF_NO_SLICES)
             return;
-        // even first index: the slice is copied as aligned dwords (two entries each)
-        cs_lo[0] = (4 * (mvmin_x - 8) - mvpx) & ~1;
-        cs_lo[1] = (4 * (mvmin_y - 8) - mvpy) & ~1;
-        s->cs_lo[0] = cs_lo[0]; s->cs_lo[1] = cs_lo[1];
+        // first index a multiple of 8 entries: the slices are copied in aligned 16-byte pieces.
+        // (A slice that would leave the table - MVDs beyond +-32767 - is not kept: lookups then
+        // go to the table, whose index wraps like the reference's int16 MVD.)
+        const int lo0 = (4 * (mvmin_x - 8) - mvpx) & ~7, lo1 = (4 * (mvmin_y - 8) - mvpy) & ~7;
+        if (lo0 < -32768 || lo0 + CS_LEN > 32768 || lo1 < -32768 || lo1 + CS_LEN > 32768)
+            return;
+        cs_lo[0] = lo0;
+        cs_lo[1] = lo1;
+        s->cs_lo[0] = lo0; s->cs_lo[1] = lo1;
+        D::post(base, D::OP_SLICES);
         D::stage_slices(base);
     }
 
     // ---------------------------------------------------------------- LDS reference window policy
     // Decide where the blocks with origins in [minx,maxx] x [miny,maxy] (with the 8-tap apron) are
     // read from: the window if it holds them; else, for a compact point set, a window re-staged
-    // around them; else the plane.  Returns CF_WINDOW or 0.
-    __device__ __forceinline__ int place(int minx, int miny, int maxx, int maxy)
+    // around them (unless the caller expects no follow-up near them); else the plane.
+    // Returns CF_WINDOW or 0.
+    __device__ __forceinline__ int place(int minx, int miny, int maxx, int maxy, bool may_restage)
     {
         if (jflags & JF_NO_WINDOW)
             return 0;
         if (wvalid && minx - 3 >= wx0 && maxx + w + 5 <= wx0 + ww && miny - 3 >= wy0 && maxy + h + 4 <= wy0 + wh)
             return CF_WINDOW;
-        if (maxx - minx > WIN_LOCAL || maxy - miny > WIN_LOCAL)
+        if (!may_restage || maxx - minx > WIN_LOCAL || maxy - miny > WIN_LOCAL)
             return 0;
+        D::post(base, D::OP_RESTAGE, minx, miny, maxx, maxy);
         if (!uni(D::restage(base, minx, miny, maxx, maxy)))
             return 0;
         wx0 = uni(s->wx0); wy0 = uni(s->wy0); ww = uni(s->ww); wh = uni(s->wh); wpitch = uni(s->wpitch);
@@ -1092,7 +1155,9 @@ struct Wave
             minx = sx[k] < minx ? sx[k] : minx; maxx = sx[k] > maxx ? sx[k] : maxx;
             miny = sy[k] < miny ? sy[k] : miny; maxy = sy[k] > maxy ? sy[k] : maxy;
         }
-        const int where = place(minx, miny, maxx, maxy);
+        const bool multi = kind == X265AMD_SAD && frac == 0;
+        // a lone full-pel SAD (predictor checks, clipped pattern points) does not move the window
+        const int where = place(minx, miny, maxx, maxy, !(N == 1 && multi));
         constexpr int NP = N == 1 ? 1 : N <= 4 ? 4 : 8;     // candidates the SAD pass measures (padding: candidate 0)
 #pragma unroll
         for (int k = 0; k < NP; k++)
@@ -1102,9 +1167,19 @@ struct Wave
                 s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
         }
         evals += N;
-        const bool multi = kind == X265AMD_SAD && frac == 0;
-        Res8 r = multi ? D::eval_sad(base, N, where | cflags | take_par(1))
-                       : D::eval_any(base, N, where | cflags | take_par(N), kind | (frac << 8));
+        Res8 r;
+        if (multi)
+        {
+            const int cf = where | cflags | take_par(1);
+            D::post(base, D::OP_SAD, N, cf);
+            r = D::eval_sad(base, N, cf);
+        }
+        else
+        {
+            const int cf = where | cflags | take_par(N);
+            D::post(base, D::OP_ANY, N, cf, kind | (frac << 8));
+            r = D::eval_any(base, N, cf, kind | (frac << 8));
+        }
 #pragma unroll
         for (int k = 0; k < N; k++)
             out[k] = uni(r.c[k]);

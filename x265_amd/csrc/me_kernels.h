@@ -50,13 +50,27 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
         return;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
+    if (L::NW > 1 && Dev<L>::wave_id() != 0)
+    {
+        Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
+        return;
+    }
     Wave<L> W;
+    W.stamp(0);
     W.bind(lds, enc, ref, j.pu_x, j.pu_y, j.pu_x, j.pu_y, j.w, j.h, P.cost[j.qp], P.flags);
+    W.stamp(1);
     Search<L> S(W, j);
     int ox, oy;
     const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(typename L::PIX))) ? fb + (size_t)id * fb_stride : nullptr;
     int cost = S.run(f, fb_stride, ox, oy);
+    Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     Dev<L>::publish(out + id, ox, oy, cost, evals, W.evals);
+#ifdef XA_PROFILE
+    W.stamp(6);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; k++)
+            atomicAdd(evals + 1 + k, (unsigned long long)(W.tstamp[k + 1] - W.tstamp[k]));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -335,6 +335,7 @@ struct Search
         int merange = j.merange;
         W.ikind = j.icost;
         W.set_mvp(j.mvmin_x, j.mvmin_y, j.qmvp_x, j.qmvp_y);      // setMVP (bitcost.h:43)
+        W.stamp(2);
         const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
         const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);
         auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };   // MV::clipped, mv.h:88-93
@@ -378,6 +379,7 @@ struct Search
         pmy = XA_S16(XA_S16(pmy + 2) >> 2);
         int omx = bmx, omy = bmy;
         bool do_hex = false;
+        W.stamp(3);
 
         switch (j.method)
         {
@@ -647,6 +649,7 @@ struct Search
             bmy = XA_S16(bmy + c_square1[sq + 1][1]);
         }
 
+        W.stamp(4);
         // motion.cpp:778-784
         if (bprecost < bcost)
         {
@@ -705,6 +708,7 @@ struct Search
             bmx = XA_S16(bmx + c_square1[bdir][0]);
             bmy = XA_S16(bmy + c_square1[bdir][1]);
         }
+        W.stamp(5);
         outx = bmx;
         outy = bmy;
         return bcost;

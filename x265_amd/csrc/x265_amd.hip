@@ -608,7 +608,7 @@ int x265amd_create(int device, x265amd_ctx **out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->d_planes, sizeof(c->h_planes))) != hipSuccess ||
         (e = hipMalloc(&c->d_cost, (size_t)52 * 65536 * sizeof(uint16_t))) != hipSuccess ||
-        (e = hipMalloc(&c->d_evals, sizeof(unsigned long long))) != hipSuccess)
+        (e = hipMalloc(&c->d_evals, 16 * sizeof(unsigned long long))) != hipSuccess)
     {
         fprintf(stderr, "x265amd_create: %s\n", hipGetErrorString(e));
         delete c;
@@ -621,7 +621,7 @@ int x265amd_create(int device, x265amd_ctx **out)
             delete c;
             return X265AMD_ERR_HIP;
         }
-    hipMemset(c->d_evals, 0, sizeof(unsigned long long));
+    hipMemset(c->d_evals, 0, 16 * sizeof(unsigned long long));
     // the exhaustive kernel uses up to 64 KiB of dynamic LDS
     const void *full_kernels[] = { (const void*)k_full_items<0>, (const void*)k_full_items<1>, (const void*)k_full_items<2>,
                                    (const void*)k_full_items<3>, (const void*)k_full_items<4>, (const void*)k_full_items<6>,
@@ -916,8 +916,16 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
     HIPCHK(c, hipMemcpy(&v, c->d_evals, sizeof(v), hipMemcpyDeviceToHost));
     if (evals)
         *evals = v;
+#ifdef XA_PROFILE
+    {
+        unsigned long long t[16];
+        HIPCHK(c, hipMemcpy(t, c->d_evals, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "phase clocks: bind %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu\n",
+                t[1], t[2], t[3], t[4], t[5], t[6]);
+    }
+#endif
     if (reset)
-        HIPCHK(c, hipMemset(c->d_evals, 0, sizeof(v)));
+        HIPCHK(c, hipMemset(c->d_evals, 0, 16 * sizeof(v)));
     return 0;
 }
 
