@@ -453,7 +453,8 @@ struct Dev
         __builtin_memcpy(&y, &b, 4);
         return __builtin_amdgcn_sdot2(x, y, acc, false);
     }
-    static __device__ __forceinline__ void filt8x4(const uint32_t *r, int f, int *out)
+    // out[i] = bias + sum_k c[k] * px[i + k] for 4 adjacent outputs over 12 packed pixels
+    static __device__ __forceinline__ void filt8x4(const uint32_t *r, int f, int bias, int *out)
     {
         if (DW == 1)
         {
@@ -464,7 +465,7 @@ struct Dev
             {
                 const uint32_t a = i ? __builtin_amdgcn_alignbyte(b1, b0, i) : b0;
                 const uint32_t b = i ? __builtin_amdgcn_alignbyte(b2, b1, i) : b1;
-                int sm = __builtin_amdgcn_sdot4((int)a, t.lo, 8192, false);
+                int sm = __builtin_amdgcn_sdot4((int)a, t.lo, 8192 + bias, false);
                 out[i] = __builtin_amdgcn_sdot4((int)b, t.hi, sm, false);
             }
         }
@@ -475,7 +476,7 @@ struct Dev
             for (int i = 0; i < 4; i++)
             {
                 // pixels i .. i+7 start at 16-bit element i: dword i/2, odd i straddles dwords
-                int sm = 0;
+                int sm = bias;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
@@ -496,8 +497,8 @@ struct Dev
         sum[2] = dot2(__builtin_amdgcn_perm(b[1], a[1], 0x05040100), taps, sum[2]);
         sum[3] = dot2(__builtin_amdgcn_perm(b[1], a[1], 0x07060302), taps, sum[3]);
     }
-    // vertical 8-tap over 8 rows of 4 packed pixels: sum[i] = sum_k c[k] * row_k[i]
-    static __device__ __forceinline__ void vfilt8x4(const uint32_t (*rw)[2], int f, int *sum)
+    // vertical 8-tap over 8 rows of 4 packed pixels: sum[i] = bias + sum_k c[k] * row_k[i]
+    static __device__ __forceinline__ void vfilt8x4(const uint32_t (*rw)[2], int f, int bias, int *sum)
     {
         if (DW == 1)
         {
@@ -516,34 +517,66 @@ struct Dev
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                sum[i] = __builtin_amdgcn_sdot4((int)col[1][i], t.hi, __builtin_amdgcn_sdot4((int)col[0][i], t.lo, 8192, false), false);
+                sum[i] = __builtin_amdgcn_sdot4((int)col[1][i], t.hi, __builtin_amdgcn_sdot4((int)col[0][i], t.lo, 8192 + bias, false), false);
         }
         else
         {
             const Taps16 t(f);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                sum[i] = 0;
+                sum[i] = bias;
 #pragma unroll
             for (int k = 0; k < 8; k += 2)
                 vpair16(rw[k], rw[k + 1], t.p[k / 2], sum);
         }
     }
+    // the reference's `short` intermediates: a no-op for 8-bit pixels, whose sums all fit 16 bits
+    static __device__ __forceinline__ int as_short(int v) { return DW == 1 ? v : (int)(int16_t)v; }
+    static __device__ __forceinline__ int clamp_pix(int v, int maxval)
+    {
+        v = v < 0 ? 0 : v;
+        return v > maxval ? maxval : v;
+    }
 
     // ------------------------------------------------------------------ Hadamard partials
+    // d = fenc - pred of this lane's 4 pixels.  The row transform is done inside the lane; the column
+    // transform runs across lanes, each stage as t = +-t + partner(t) with the sign a per-lane
+    // constant.  With 8-bit pixels every intermediate of the 4x4 and 8x8 transforms fits 16 bits, so
+    // the cross-lane stages, the absolute values and the sums work on two values per register.
 
-    // per-lane |Hadamard| partial sums of one pass for SATD: d = fenc - pred of this lane's 4 pixels
+    static __device__ __forceinline__ short2v as_s2(int v) { short2v r; __builtin_memcpy(&r, &v, 4); return r; }
+    static __device__ __forceinline__ int as_i(short2v v) { int r; __builtin_memcpy(&r, &v, 4); return r; }
+    template <int CTRL> static __device__ __forceinline__ short2v dpp2(short2v v) { return as_s2(dpp<CTRL>(as_i(v))); }
+    static __device__ __forceinline__ int abs_sum2(short2v a, short2v b)      // |a.x| + |a.y| + |b.x| + |b.y|
+    {
+        typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+        const short2v ma = __builtin_elementwise_max(a, -a), mb = __builtin_elementwise_max(b, -b);
+        ushort2v ua, ub, one = { 1, 1 };
+        __builtin_memcpy(&ua, &ma, 4);
+        __builtin_memcpy(&ub, &mb, 4);
+        return (int)__builtin_amdgcn_udot2(ua, one, __builtin_amdgcn_udot2(ub, one, 0u, false), false);
+    }
+
+    // per-lane |Hadamard| partial sums of one pass for SATD (4 lanes = the 4 rows of a 4x4 tile)
     static __device__ __forceinline__ int had4_partial(const int *d, int lane)
     {
         int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
         int v[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+        if (DW == 1)
+        {
+            const short2v s1 = as_s2((lane & 1) ? -1 : 0x00010001), s2 = as_s2((lane & 2) ? -1 : 0x00010001);
+            short2v p = as_s2(__builtin_amdgcn_perm(v[1], v[0], 0x05040100)), q = as_s2(__builtin_amdgcn_perm(v[3], v[2], 0x05040100));
+            p = p * s1 + dpp2<0xB1>(p); q = q * s1 + dpp2<0xB1>(q);      // lanes ^1: rows r, r^1 -> sum / difference
+            p = p * s2 + dpp2<0x4E>(p); q = q * s2 + dpp2<0x4E>(q);      // lanes ^2
+            return abs_sum2(p, q);
+        }
         const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1;
         int s = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            int t = v[i] * s1 + xor1(v[i]);          // lanes ^1: rows r, r^1  ->  sum / difference
-            t = t * s2 + xor2(t);                    // lanes ^2
+            int t = v[i] * s1 + xor1(v[i]);
+            t = t * s2 + xor2(t);
             s += t < 0 ? -t : t;
         }
         return s;
@@ -554,14 +587,25 @@ struct Dev
     {
         int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
         int v[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+        if (DW == 1)
+        {
+            const short2v s1 = as_s2((lane & 1) ? -1 : 0x00010001), s2 = as_s2((lane & 2) ? -1 : 0x00010001);
+            const short2v s4 = as_s2((lane & 4) ? -1 : 0x00010001), s8 = as_s2((lane & 8) ? -1 : 0x00010001);
+            short2v p = as_s2(__builtin_amdgcn_perm(v[1], v[0], 0x05040100)), q = as_s2(__builtin_amdgcn_perm(v[3], v[2], 0x05040100));
+            p = p * s4 + as_s2(xor4(as_i(p))); q = q * s4 + as_s2(xor4(as_i(q)));   // horizontal: the two 4-pixel halves
+            p = p * s1 + dpp2<0xB1>(p);  q = q * s1 + dpp2<0xB1>(q);                // vertical: rows ^1, ^2, ^4
+            p = p * s2 + dpp2<0x4E>(p);  q = q * s2 + dpp2<0x4E>(q);
+            p = p * s8 + dpp2<0x128>(p); q = q * s8 + dpp2<0x128>(q);
+            return abs_sum2(p, q);
+        }
         const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1, s4 = (lane & 4) ? -1 : 1, s8 = (lane & 8) ? -1 : 1;
         int s = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
             int t = v[i];
-            t = t * s4 + xor4(t);                    // horizontal: the two 4-pixel halves
-            t = t * s1 + xor1(t);                    // vertical: rows ^1, ^2, ^4
+            t = t * s4 + xor4(t);
+            t = t * s1 + xor1(t);
             t = t * s2 + xor2(t);
             t = t * s8 + xor8(t);
             s += t < 0 ? -t : t;
@@ -704,7 +748,7 @@ struct Dev
     // element `ioff`.  `mode` is uniform: the switch is a scalar branch.
     template <bool LW>
     static __device__ __forceinline__ P4 pred4(const View &v, const Src &src, int mode, int off, int pitch, int ioff, int w,
-                                               int depth, int xf, int yf)
+                                               int depth_rt, int xf, int yf)
     {
         constexpr int step = LW ? PB : 1;
         if (mode == PRED_INT)
@@ -713,6 +757,7 @@ struct Dev
             src.template rd4_packed<LW>(off, d);
             return unpack4(d);
         }
+        const int depth = DW == 1 ? 8 : depth_rt;     // 8-bit planes: every shift and bound is a constant
         const int hr = 14 - depth;
         const int maxval = (1 << depth) - 1;
         P4 r;
@@ -721,16 +766,10 @@ struct Dev
             uint32_t px[6];
             src.template rd12_packed<LW>(off - 3 * step, px);
             int sum[4];
-            filt8x4(px, xf, sum);
-            const int offset = 1 << (hr - 1);
+            filt8x4(px, xf, 1 << (hr - 1), sum);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-            {
-                int val = (int)(int16_t)(sum[i] + offset) >> hr;
-                val = (int16_t)val;
-                val = val < 0 ? 0 : val;
-                r.v[i] = val > maxval ? maxval : val;
-            }
+                r.v[i] = clamp_pix(as_short(as_short(sum[i]) >> hr), maxval);
             return r;
         }
         if (mode == PRED_V)        // filterVertical_p_p, ipfilter.cpp:354-425
@@ -740,14 +779,10 @@ struct Dev
             for (int k = 0; k < 8; k++)
                 src.template rd4_packed<LW>(off + (k - 3) * pitch, rw[k]);
             int sum[4];
-            vfilt8x4(rw, yf, sum);
+            vfilt8x4(rw, yf, 32, sum);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-            {
-                int val = (int16_t)((sum[i] + 32) >> 6);
-                val = val < 0 ? 0 : val;
-                r.v[i] = val > maxval ? maxval : val;
-            }
+                r.v[i] = clamp_pix(as_short(sum[i] >> 6), maxval);
             return r;
         }
         // PRED_HV, second half: filterVertical_s_p (ipfilter.cpp:38-89) over the LDS intermediate,
@@ -757,7 +792,7 @@ struct Dev
             const int off3 = (1 << (sh3 - 1)) + (8192 << 6);
             const XA_LDS int16_t *m = v.l->imm + ioff;
             const Taps16 ty(yf);
-            int sum[4] = { 0, 0, 0, 0 };
+            int sum[4] = { off3, off3, off3, off3 };
 #pragma unroll
             for (int k = 0; k < 8; k += 2)
             {
@@ -768,11 +803,7 @@ struct Dev
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
-            {
-                int val = (int16_t)((sum[i] + off3) >> sh3);
-                val = val < 0 ? 0 : val;
-                r.v[i] = val > maxval ? maxval : val;
-            }
+                r.v[i] = clamp_pix(as_short(sum[i] >> sh3), maxval);
             return r;
         }
     }
@@ -780,10 +811,11 @@ struct Dev
     // candidate block, shared by all lanes through LDS (as the reference shares immedVal,
     // encoder/motion.cpp:1158-1161)
     template <bool LW>
-    static __device__ __forceinline__ void stage_hv(const View &v, const Src &src, int off, int pitch, int w, int h, int depth,
+    static __device__ __forceinline__ void stage_hv(const View &v, const Src &src, int off, int pitch, int w, int h, int depth_rt,
                                                     int xf)
     {
         constexpr int step = LW ? PB : 1;
+        const int depth = DW == 1 ? 8 : depth_rt;
         const int hr = 14 - depth;
         const int sh2 = 6 - hr;
         const int off2 = -8192 * (1 << sh2);
@@ -795,16 +827,12 @@ struct Dev
             uint32_t px[6];
             src.template rd12_packed<LW>(off + (row - 3) * pitch + (col - 3) * step, px);
             int sm[4];
-            filt8x4(px, xf, sm);
-            uint32_t pk[2];
+            filt8x4(px, xf, off2, sm);
 #pragma unroll
-            for (int i = 0; i < 4; i += 2)
-            {
-                const int h0 = (int16_t)((int)(int16_t)(sm[i] + off2) >> sh2);
-                const int h1 = (int16_t)((int)(int16_t)(sm[i + 1] + off2) >> sh2);
-                pk[i / 2] = (uint32_t)(h0 & 0xffff) | ((uint32_t)h1 << 16);
-            }
-            *(XA_LDS uint64_t*)(v.l->imm + row * w + col) = (uint64_t)pk[0] | ((uint64_t)pk[1] << 32);
+            for (int i = 0; i < 4; i++)
+                sm[i] = as_short(as_short(sm[i]) >> sh2);
+            const uint32_t lo = __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100), hi = __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100);
+            *(XA_LDS uint64_t*)(v.l->imm + row * w + col) = (uint64_t)lo | ((uint64_t)hi << 32);
         }
         bsync();
     }
