@@ -728,6 +728,10 @@ struct Dev
 #pragma unroll
                 for (int k = 0; k < N; k++)
                 {
+                    // (large workgroups: keep at most 4 candidates' loads in flight, so that the
+                    // function fits the 64 registers two 1024-thread workgroups per CU allow)
+                    if (NW >= 16 && k == 4)
+                        __builtin_amdgcn_sched_barrier(0);
                     uint32_t r[2];
                     src.template rd4_packed<LW>(p[k] + lo, r);
                     if (DW == 1)
@@ -796,6 +800,8 @@ struct Dev
 #pragma unroll
             for (int k = 0; k < 8; k += 2)
             {
+                if (NW >= 16 && k == 4)
+                    __builtin_amdgcn_sched_barrier(0);      // (register budget of large workgroups, see sad_loop)
                 const uint64_t d0 = *(const XA_LDS uint64_t*)(m + k * w);
                 const uint64_t d1 = *(const XA_LDS uint64_t*)(m + (k + 1) * w);
                 const uint32_t a[2] = { (uint32_t)d0, (uint32_t)(d0 >> 32) }, b[2] = { (uint32_t)d1, (uint32_t)(d1 >> 32) };

@@ -251,7 +251,7 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
 {
     // the large PUs first: they are the long-running workgroups
     if (cnt[2] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 16, 1024>>), dim3(cnt[2]), dim3(1024), 0, c->stream, P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024>>), dim3(cnt[2]), dim3(512), 0, c->stream, P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256>>), dim3(cnt[1]), dim3(256), 0, c->stream, P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
