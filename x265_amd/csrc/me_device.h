@@ -227,6 +227,7 @@ struct JobState
     int32_t  wpitch, pad;           // its pitch in bytes
     int32_t  pts[8];                // candidates of the next eval call: offset of the block origin (window bytes / plane pixels)
     int32_t  lbl[8];                // their labels for MV pricing: (y << 16) | (x & 0xffff), q-pel
+    int32_t  frc[8];                // their fractional phases xf | yf << 2 (eval_any)
 };
 
 // LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64)
@@ -240,7 +241,7 @@ struct JobLds
 
     uint32_t fenc[MAXG * DW];                   // encoder pixels of group g (cached PU, encoder/motion.cpp:104-119)
     uint16_t gxy[MAXG];                         // (y << 8) | x of group g inside the PU
-    int16_t  imm[MAXG * 4 + 7 * 64];            // horizontally filtered rows -3..h+3 of an HV candidate (stride w)
+    int16_t  imm[MAXG * 4 + 8 * 64];            // horizontally filtered rows -3..h+4 of an HV candidate (stride w)
     int      red[2][8][NW];                     // cross-wave partial sums: [parity][value][wave]
     uint32_t cs[2][CS_LEN / 2];                 // MV-cost slices (uint16 entries): cost[lo_x + i], cost[lo_y + i]
     uint32_t win[WIN_BYTES / 4 + 4];            // reference window
@@ -813,9 +814,11 @@ struct Dev
             return r;
         }
     }
-    // PRED_HV, first half: filterHorizontal_p_s (ipfilter.cpp:265-309) of rows -3 .. h+3 of the
+    // PRED_HV, first half: filterHorizontal_p_s (ipfilter.cpp:265-309) of rows -3 .. h+4 of the
     // candidate block, shared by all lanes through LDS (as the reference shares immedVal,
-    // encoder/motion.cpp:1158-1161)
+    // encoder/motion.cpp:1158-1161).  One row more than a candidate needs: the candidate one row
+    // below with the same horizontal phase (the other diagonal neighbour of a refinement round)
+    // then reuses the intermediate.
     template <bool LW>
     static __device__ __forceinline__ void stage_hv(const View &v, const Src &src, int off, int pitch, int w, int h, int depth_rt,
                                                     int xf)
@@ -826,7 +829,7 @@ struct Dev
         const int sh2 = 6 - hr;
         const int off2 = -8192 * (1 << sh2);
         const int ngx = w >> 2;
-        const int n = (h + 7) * ngx;
+        const int n = (h + 8) * ngx;
         for (int idx = v.tid; idx < n; idx += NT)
         {
             const int row = idx / ngx, col = (idx - row * ngx) * 4;
@@ -848,17 +851,27 @@ struct Dev
     // (xf,yf): subpelCompare for a full-resolution reference (encoder/motion.cpp:1140-1165) when the
     // phase is non-zero.  One body for all kinds and interpolation modes (uniform switches) keeps
     // the instruction footprint small.
+    struct HvCache { int off, xf; bool valid; };    // which horizontal intermediate LDS holds (uniform)
+
     static __device__ __forceinline__ int cost_body(View &v, const Src &src, bool lw, int off, int pitch, int xf, int yf,
-                                                    int kind, int par)
+                                                    int kind, int par, HvCache &hc)
     {
         const int w = uni(v.s->w), h = uni(v.s->h), depth = v.s->depth;
         const int mode = (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
         const bool m8 = ((w | h) & 7) == 0;
         const bool m16 = ((w | h) & 15) == 0;
+        int hv_row = 0;             // first intermediate row of this candidate
         if (mode == PRED_HV)
         {
-            if (lw) stage_hv<true>(v, src, off, pitch, w, h, depth, xf);
-            else    stage_hv<false>(v, src, off, pitch, w, h, depth, xf);
+            const int uoff = uni(off), upitch = uni(pitch);
+            if (hc.valid && hc.xf == xf && (uoff == hc.off || uoff == hc.off + upitch))
+                hv_row = uoff != hc.off;
+            else
+            {
+                if (lw) stage_hv<true>(v, src, off, pitch, w, h, depth, xf);
+                else    stage_hv<false>(v, src, off, pitch, w, h, depth, xf);
+                hc.off = uoff; hc.xf = xf; hc.valid = true;
+            }
         }
         // which accumulation: 0 sad, 1 4x4 Hadamard (halved at the end), 2 8x8 with 8x8 rounding, 3 8x8 with 16x16 rounding
         const int am = kind == X265AMD_SAD ? 0 : (kind == X265AMD_SATD || !m8) ? 1 : (m16 ? 3 : 2);
@@ -876,8 +889,8 @@ struct Dev
                     fd[1] = v.l->fenc[DW * g + 1];
                 const P4 f = unpack4(fd);
                 const int lo = off + gy * pitch + gx * (lw ? PB : 1);
-                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, gy * w + gx, w, depth, xf, yf)
-                                : pred4<false>(v, src, mode, lo, pitch, gy * w + gx, w, depth, xf, yf);
+                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf)
+                                : pred4<false>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     d[i] = f.v[i] - r.v[i];
@@ -975,22 +988,22 @@ struct Dev
         return r;
     }
 
-    // eval_any: any cost kind and phase (frac = xf | yf << 2, the same for all candidates), one
-    // cost_body per candidate.
-    static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_frac_)
+    // eval_any: any cost kind, each candidate with its own phase (JobState::frc), one cost_body per
+    // candidate.
+    static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_)
     {
-        const int n = uni(n_), cflags = uni(cflags_);
-        const int kind = uni(kind_frac_) & 0xff, frac = uni(kind_frac_) >> 8;
+        const int n = uni(n_), cflags = uni(cflags_), kind = uni(kind_);
         View v(base);
         const bool lw = (cflags & CF_WINDOW) != 0;
         const int pitch = lw ? v.s->wpitch : v.s->stride;
         Src src(v, lw);
         int res = label_cost(v, n, cflags);     // lane k collects candidate k
         int par = (cflags & CF_PAR) ? 1 : 0;
+        HvCache hc = { 0, 0, false };
         for (int k = 0; k < n; k++)
         {
-            const int off = v.s->pts[k];
-            const int c = cost_body(v, src, lw, off, pitch, frac & 3, frac >> 2, kind, par);
+            const int off = v.s->pts[k], frac = uni(v.s->frc[k]);
+            const int c = cost_body(v, src, lw, off, pitch, frac & 3, frac >> 2, kind, par, hc);
             res += (v.lane == k) ? c : 0;
             par ^= 1;
         }
@@ -1176,43 +1189,57 @@ struct Wave
         return p;
     }
 
-    // Costs of N candidate blocks with full-pel origins (sx,sy)[k], all of kind `kind` and phase
-    // `frac`, plus (unless CF_NOMV) the MV costs of the q-pel labels (qx,qy)[k].
+    // Costs of the first n of N candidate blocks with full-pel origins (sx,sy)[k], of kind `kind`
+    // and phases frac[k] (NULL: all full-pel), plus (unless CF_NOMV) the MV costs of the q-pel
+    // labels (qx,qy)[k].
     template <int N>
-    __device__ __forceinline__ void eval_n(const int *sx, const int *sy, const int *qx, const int *qy, int kind, int frac,
-                                           int cflags, int *out)
+    __device__ __forceinline__ void eval_n(int n, const int *sx, const int *sy, const int *qx, const int *qy, int kind,
+                                           const int *frac, int cflags, int *out)
     {
+        // bounding box of the origins (entries >= n repeat candidate 0, also as padding for the callee)
         int minx = sx[0], maxx = sx[0], miny = sy[0], maxy = sy[0];
 #pragma unroll
         for (int k = 1; k < N; k++)
         {
-            minx = sx[k] < minx ? sx[k] : minx; maxx = sx[k] > maxx ? sx[k] : maxx;
-            miny = sy[k] < miny ? sy[k] : miny; maxy = sy[k] > maxy ? sy[k] : maxy;
+            const int x = k < n ? sx[k] : sx[0], y = k < n ? sy[k] : sy[0];
+            minx = x < minx ? x : minx; maxx = x > maxx ? x : maxx;
+            miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
         }
-        const bool multi = kind == X265AMD_SAD && frac == 0;
+        const bool multi = kind == X265AMD_SAD && !frac;
         // a lone full-pel SAD (predictor checks, clipped pattern points) does not move the window
         const int where = place(minx, miny, maxx, maxy, !(N == 1 && multi));
-        constexpr int NP = N == 1 ? 1 : N <= 4 ? 4 : 8;     // candidates the SAD pass measures (padding: candidate 0)
+        constexpr int NP = N == 1 ? 1 : N <= 4 ? 4 : 8;     // candidates the SAD pass measures
 #pragma unroll
         for (int k = 0; k < NP; k++)
         {
-            s->pts[k] = block_off(where, sx[k < N ? k : 0], sy[k < N ? k : 0]);
+            const bool real = k < N && k < n;
+            s->pts[k] = block_off(where, real ? sx[k < N ? k : 0] : sx[0], real ? sy[k < N ? k : 0] : sy[0]);
             if (k < N)
+            {
                 s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
+                if (frac)
+                    s->frc[k] = frac[k];
+            }
         }
-        evals += N;
+        evals += (unsigned)n;
         Res8 r;
         if (multi)
         {
             const int cf = where | cflags | take_par(1);
-            D::post(base, D::OP_SAD, N, cf);
-            r = D::eval_sad(base, N, cf);
+            D::post(base, D::OP_SAD, n, cf);
+            r = D::eval_sad(base, n, cf);
         }
         else
         {
-            const int cf = where | cflags | take_par(N);
-            D::post(base, D::OP_ANY, N, cf, kind | (frac << 8));
-            r = D::eval_any(base, N, cf, kind | (frac << 8));
+            const int cf = where | cflags | take_par(n);
+            if (!frac)
+            {
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    s->frc[k] = 0;
+            }
+            D::post(base, D::OP_ANY, n, cf, kind);
+            r = D::eval_any(base, n, cf, kind);
         }
 #pragma unroll
         for (int k = 0; k < N; k++)
@@ -1234,7 +1261,7 @@ struct Wave
             qx[k] = (int16_t)((int16_t)lx[k] << sh);
             qy[k] = (int16_t)((int16_t)ly[k] << sh);
         }
-        eval_n<N>(sx, sy, qx, qy, ikind, 0, pflags, out);
+        eval_n<N>(N, sx, sy, qx, qy, ikind, nullptr, pflags, out);
     }
 
     // COST_MV's value: cost at full-pel (mx,my) + mvcost(MV(mx,my) << 2)   (motion.cpp:173-179)
@@ -1249,10 +1276,23 @@ struct Wave
     // with_mv: plus mvcost(MV(qx,qy))
     __device__ __forceinline__ int subpel_cost(int qx, int qy, int kind, bool with_mv)
     {
-        const int cx = qx >> 2, cy = qy >> 2;
+        const int cx = qx >> 2, cy = qy >> 2, fr = (qx & 3) | ((qy & 3) << 2);
         int c;
-        eval_n<1>(&cx, &cy, &qx, &qy, kind, (qx & 3) | ((qy & 3) << 2), with_mv ? 0 : CF_NOMV, &c);
+        eval_n<1>(1, &cx, &cy, &qx, &qy, kind, &fr, with_mv ? 0 : CF_NOMV, &c);
         return c;
+    }
+    // the same for the first n of 8 q-pel positions at once, each plus its MV cost: one refinement
+    // round (motion.cpp:801-845) in a single call
+    __device__ __forceinline__ void subpel_cost8(int n, const int *qx, const int *qy, int kind, int *out)
+    {
+        int cx[8], cy[8], fr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            cx[k] = qx[k] >> 2; cy[k] = qy[k] >> 2;
+            fr[k] = (qx[k] & 3) | ((qy[k] & 3) << 2);
+        }
+        eval_n<8>(n, cx, cy, qx, qy, kind, fr, 0, out);
     }
 
     // plain block cost against the block at the reference origin
@@ -1260,7 +1300,7 @@ struct Wave
     {
         const int z = 0;
         int c;
-        eval_n<1>(&z, &z, &z, &z, kind, 0, CF_NOMV, &c);
+        eval_n<1>(1, &z, &z, &z, &z, kind, &z, CF_NOMV, &c);
         return c;
     }
 };

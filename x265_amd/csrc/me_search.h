@@ -670,21 +670,26 @@ struct Search
         const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
         if (wl[4])
             bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
+        // Each round prices its 4 or 8 neighbours in one call; they are then taken in the reference's
+        // order with its strict comparison.
 #pragma nounroll
         for (int it = 0; it < wl[0]; it++)
         {
-            int bdir = 0;
-#pragma nounroll
-            for (int i = 1; i <= wl[1]; i++)
+            int qx[8], qy[8], c[8], bdir = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
             {
-                int qx = XA_S16(bmx + c_square1[i][0] * 2), qy = XA_S16(bmy + c_square1[i][1] * 2);
-                int c = W.subpel_cost(qx, qy, hkind, true);
-                if (c < bcost)
-                {
-                    bcost = c;
-                    bdir = i;
-                }
+                qx[i] = XA_S16(bmx + c_square1[i + 1][0] * 2);
+                qy[i] = XA_S16(bmy + c_square1[i + 1][1] * 2);
             }
+            W.subpel_cost8(wl[1], qx, qy, hkind, c);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < wl[1] && c[i] < bcost)
+                {
+                    bcost = c[i];
+                    bdir = i + 1;
+                }
             bmx = XA_S16(bmx + c_square1[bdir][0] * 2);
             bmy = XA_S16(bmy + c_square1[bdir][1] * 2);
         }
@@ -693,18 +698,21 @@ struct Search
 #pragma nounroll
         for (int it = 0; it < wl[2]; it++)
         {
-            int bdir = 0;
-#pragma nounroll
-            for (int i = 1; i <= wl[3]; i++)
+            int qx[8], qy[8], c[8], bdir = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
             {
-                int qx = XA_S16(bmx + c_square1[i][0]), qy = XA_S16(bmy + c_square1[i][1]);
-                int c = W.subpel_cost(qx, qy, X265AMD_SATD, true);
-                if (c < bcost)
-                {
-                    bcost = c;
-                    bdir = i;
-                }
+                qx[i] = XA_S16(bmx + c_square1[i + 1][0]);
+                qy[i] = XA_S16(bmy + c_square1[i + 1][1]);
             }
+            W.subpel_cost8(wl[3], qx, qy, X265AMD_SATD, c);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < wl[3] && c[i] < bcost)
+                {
+                    bcost = c[i];
+                    bdir = i + 1;
+                }
             bmx = XA_S16(bmx + c_square1[bdir][0]);
             bmy = XA_S16(bmy + c_square1[bdir][1]);
         }
