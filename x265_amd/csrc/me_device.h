@@ -195,7 +195,8 @@ __device__ __forceinline__ void group_xy(int g, int w, int h, int &x, int &y)
 
 enum { PRED_INT = 0, PRED_H = 1, PRED_V = 2, PRED_HV = 3 };
 
-constexpr int CS_LEN = 640;         // entries per MV-cost slice kept in LDS (covers merange 64 in q-pel units + slack)
+constexpr int CS_LEN = 160;         // entries of the MV-cost slice kept in LDS: MVDs within +-20 pixels of the predictor
+constexpr int CS_LO = -CS_LEN / 2;  // MVD of its first entry (a multiple of 8: 16-byte aligned copies)
 constexpr int WIN_MARGIN = 8;       // pixels of search excursion the LDS reference window keeps around a staging centre
 constexpr int WIN_LOCAL = 6;        // a point set no wider than this re-centres the window; wider ones read the plane
 
@@ -222,7 +223,7 @@ struct JobState
     int32_t  stride, depth;
     int32_t  w, h, G, T;            // PU size, 4-pixel groups, passes over the job's lanes
     int32_t  mvpx, mvpy;            // q-pel predictor the MV costs are relative to
-    int32_t  cs_lo[2];              // MVD of entry 0 of the x / y cost slice
+    int32_t  sliced, pad0;          // the LDS cost slice is staged
     int32_t  wx0, wy0, ww, wh;      // reference window as last staged: origin relative to the PU origin, size (pixels)
     int32_t  wpitch, pad;           // its pitch in bytes
     int32_t  pts[8];                // candidates of the next eval call: offset of the block origin (window bytes / plane pixels)
@@ -236,14 +237,14 @@ struct JobLds
 {
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
-    // window bytes for 8-bit pixels: worst PU shape of the class with the full margin
-    static constexpr int WIN_BYTES = (MAXG >= 1024 ? 8704 : MAXG >= 256 ? 4352 : 3328) * (int)sizeof(PIX);
+    // window bytes for 8-bit pixels: the square PU of the class with the full margin (long thin PUs get less margin)
+    static constexpr int WIN_BYTES = (MAXG >= 1024 ? 8704 : MAXG >= 256 ? 4352 : 2560) * (int)sizeof(PIX);
 
     uint32_t fenc[MAXG * DW];                   // encoder pixels of group g (cached PU, encoder/motion.cpp:104-119)
     uint16_t gxy[MAXG];                         // (y << 8) | x of group g inside the PU
     int16_t  imm[MAXG * 4 + 8 * 64];            // horizontally filtered rows -3..h+4 of an HV candidate (stride w)
     int      red[2][8][NW];                     // cross-wave partial sums: [parity][value][wave]
-    uint32_t cs[2][CS_LEN / 2];                 // MV-cost slices (uint16 entries): cost[lo_x + i], cost[lo_y + i]
+    uint32_t cs[CS_LEN / 2];                    // MV-cost slice (uint16 entries): cost[CS_LO + i], used for both axes
     uint32_t win[WIN_BYTES / 4 + 4];            // reference window
     JobState st;
     int      cmd[8];                            // command posted by the leader wave: op, arguments (NW > 1)
@@ -643,19 +644,15 @@ struct Dev
         bsync();
     }
 
-    // copy the slices [cs_lo, cs_lo + CS_LEN) of the MV cost table into LDS (cs_lo: multiples of 8
-    // entries, so that both sides are 16-byte aligned)
+    // copy the slice [CS_LO, CS_LO + CS_LEN) of the MV cost table into LDS
     static __device__ __noinline__ void stage_slices(uint32_t base)
     {
         View v(base);
         const uint16_t *cost = (const uint16_t*)uni64(v.s->cost);
-        const int lo[2] = { uni(v.s->cs_lo[0]), uni(v.s->cs_lo[1]) };
-        constexpr int PER_AXIS = CS_LEN / 8;                 // 16-byte pieces per slice
-        for (int i = v.tid; i < 2 * PER_AXIS; i += NT)
+        for (int i = v.tid; i < CS_LEN / 8; i += NT)         // 16-byte pieces
         {
-            const int axis = i >= PER_AXIS, k = i - axis * PER_AXIS;
-            const uint4 d = *(const uint4*)(cost + lo[axis] + 8 * k);
-            XA_LDS uint32_t *q = &v.l->cs[axis][4 * k];
+            const uint4 d = *(const uint4*)(cost + CS_LO + 8 * i);
+            XA_LDS uint32_t *q = &v.l->cs[4 * i];
             q[0] = d.x; q[1] = d.y; q[2] = d.z; q[3] = d.w;
         }
         bsync();
@@ -729,9 +726,9 @@ struct Dev
 #pragma unroll
                 for (int k = 0; k < N; k++)
                 {
-                    // (large workgroups: keep at most 4 candidates' loads in flight, so that the
-                    // function fits the 64 registers two 1024-thread workgroups per CU allow)
-                    if (NW >= 16 && k == 4)
+                    // (at most 4 candidates' loads in flight: keeps the function within 64 registers,
+                    // i.e. 8 waves per SIMD)
+                    if (k == 4)
                         __builtin_amdgcn_sched_barrier(0);
                     uint32_t r[2];
                     src.template rd4_packed<LW>(p[k] + lo, r);
@@ -801,8 +798,6 @@ struct Dev
 #pragma unroll
             for (int k = 0; k < 8; k += 2)
             {
-                if (NW >= 16 && k == 4)
-                    __builtin_amdgcn_sched_barrier(0);      // (register budget of large workgroups, see sad_loop)
                 const uint64_t d0 = *(const XA_LDS uint64_t*)(m + k * w);
                 const uint64_t d1 = *(const XA_LDS uint64_t*)(m + (k + 1) * w);
                 const uint32_t a[2] = { (uint32_t)d0, (uint32_t)(d0 >> 32) }, b[2] = { (uint32_t)d1, (uint32_t)(d1 >> 32) };
@@ -934,10 +929,10 @@ struct Dev
             const int lb = v.s->lbl[v.lane];
             const int dx = (int16_t)((int16_t)lb - v.s->mvpx), dy = (int16_t)((lb >> 16) - v.s->mvpy);
             const uint16_t *tab = (const uint16_t*)v.s->cost;
-            const unsigned ix = (unsigned)(dx - v.s->cs_lo[0]), iy = (unsigned)(dy - v.s->cs_lo[1]);
-            const XA_LDS uint16_t *cs = (const XA_LDS uint16_t*)&v.l->cs[0][0];
-            int a = ix < (unsigned)CS_LEN ? cs[ix] : tab[dx];
-            int b = iy < (unsigned)CS_LEN ? cs[CS_LEN + iy] : tab[dy];
+            const unsigned ix = (unsigned)(dx - CS_LO), iy = (unsigned)(dy - CS_LO);
+            const XA_LDS uint16_t *cs = (const XA_LDS uint16_t*)&v.l->cs[0];
+            int a = (v.s->sliced && ix < (unsigned)CS_LEN) ? cs[ix] : tab[dx];
+            int b = (v.s->sliced && iy < (unsigned)CS_LEN) ? cs[iy] : tab[dy];
             mv = (cflags & CF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
         }
         return mv;
@@ -1071,7 +1066,7 @@ struct Wave
     typename D::LP l;
     typename D::SP s;
     int w, h, stride, mvpx, mvpy, ikind, jflags;
-    int cs_lo[2];
+    bool sliced;                    // the LDS cost slice is staged
     const uint16_t *cost;
     int wx0, wy0, ww, wh, wpitch;   // reference window: origin relative to the PU origin, size (pixels), pitch (bytes)
     bool wvalid;
@@ -1097,7 +1092,7 @@ struct Wave
         ikind = X265AMD_SAD;
         jflags = flags;
         mvpx = mvpy = 0;
-        cs_lo[0] = cs_lo[1] = 0x7fffffff;
+        sliced = false;
         wvalid = false;
         wx0 = wy0 = ww = wh = wpitch = 0;
         par = 0;
@@ -1111,46 +1106,39 @@ struct Wave
         s->stride = ref.stride; s->depth = ref.depth;
         s->w = w; s->h = h; s->G = G; s->T = (G + NT - 1) / NT;
         s->mvpx = 0; s->mvpy = 0;
-        s->cs_lo[0] = s->cs_lo[1] = 0x7fffffff;
+        s->sliced = 0;
         const PIX *e = (const PIX*)enc.origin + (int64_t)enc_y * enc.stride + enc_x;
         D::post(base, D::OP_FILL, (int)(uint32_t)(uint64_t)e, (int)((uint64_t)e >> 32), enc.stride);
         D::fill_pu(base, (uint64_t)e, enc.stride);
     }
 
-    // MV cost table entry for MVD `mvd` on an axis: from the LDS slice when inside it
-    __device__ __forceinline__ int cost_entry(int axis, int mvd) const
+    // MV cost table entry for MVD `mvd`: from the LDS slice when inside it
+    __device__ __forceinline__ int cost_entry(int mvd) const
     {
-        unsigned i = (unsigned)(mvd - cs_lo[axis]);
-        if (i < (unsigned)CS_LEN)
-            return uni(((const XA_LDS uint16_t*)&l->cs[0][0])[axis * CS_LEN + i]);
+        unsigned i = (unsigned)(mvd - CS_LO);
+        if (sliced && i < (unsigned)CS_LEN)
+            return uni(((const XA_LDS uint16_t*)&l->cs[0])[i]);
         return uni(cost[(int16_t)mvd]);
     }
     // mvcost(MV(x,y)) for q-pel x,y: uint16 sum of two table entries (encoder/bitcost.h:46)
     __device__ __forceinline__ int mvcost(int x, int y) const
     {
-        int a = cost_entry(0, (int16_t)(x - mvpx));
-        int b = cost_entry(1, (int16_t)(y - mvpy));
+        int a = cost_entry((int16_t)(x - mvpx));
+        int b = cost_entry((int16_t)(y - mvpy));
         return (a + b) & 0xffff;
     }
 
-    // setMVP (encoder/bitcost.h:43) + keep the part of the MV-cost table the search will index in
-    // LDS: MVDs of q-pel MVs in [4*(mvmin-8), ...) relative to the predictor
-    __device__ __forceinline__ void set_mvp(int mvmin_x, int mvmin_y, int mvpx_, int mvpy_)
+    // setMVP (encoder/bitcost.h:43) + keep the part of the MV-cost table around MVD 0 in LDS: the
+    // search mostly prices MVs near the predictor (anything else is looked up in the table)
+    __device__ __forceinline__ void set_mvp(int mvpx_, int mvpy_)
     {
         mvpx = mvpx_;
         mvpy = mvpy_;
         s->mvpx = mvpx; s->mvpy = mvpy;
         if (jflags & JF_NO_SLICES)
             return;
-        // first index a multiple of 8 entries: the slices are copied in aligned 16-byte pieces.
-        // (A slice that would leave the table - MVDs beyond +-32767 - is not kept: lookups then
-        // go to the table, whose index wraps like the reference's int16 MVD.)
-        const int lo0 = (4 * (mvmin_x - 8) - mvpx) & ~7, lo1 = (4 * (mvmin_y - 8) - mvpy) & ~7;
-        if (lo0 < -32768 || lo0 + CS_LEN > 32768 || lo1 < -32768 || lo1 + CS_LEN > 32768)
-            return;
-        cs_lo[0] = lo0;
-        cs_lo[1] = lo1;
-        s->cs_lo[0] = lo0; s->cs_lo[1] = lo1;
+        sliced = true;
+        s->sliced = 1;
         D::post(base, D::OP_SLICES);
         D::stage_slices(base);
     }

@@ -34,6 +34,7 @@ __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
 // search logic, barriers - overlap another's pixel work).  `idx` (optional) lists the jobs of
 // this launch; without it every job is visited and those of the other classes are skipped.
 constexpr int JOB_CLASSES = 3;
+constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-out)
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
 
 template <class L>
@@ -65,12 +66,13 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
     const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(typename L::PIX))) ? fb + (size_t)id * fb_stride : nullptr;
     int cost = S.run(f, fb_stride, ox, oy);
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
-    Dev<L>::publish(out + id, ox, oy, cost, evals, W.evals);
+    // (evaluation counts go to one of EVAL_SLOTS counters, 128 bytes apart, to spread the atomics)
+    Dev<L>::publish(out + id, ox, oy, cost, evals + (blockIdx.x % EVAL_SLOTS) * 16, W.evals);
 #ifdef XA_PROFILE
     W.stamp(6);
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)      // (a sample: every job would serialise on the atomics)
         for (int k = 0; k < 6; k++)
-            atomicAdd(evals + 1 + k, (unsigned long long)(W.tstamp[k + 1] - W.tstamp[k]));
+            atomicAdd(evals + EVAL_SLOTS * 16 + k, (unsigned long long)(W.tstamp[k + 1] - W.tstamp[k]));
 #endif
 }
 

@@ -334,7 +334,7 @@ struct Search
     {
         int merange = j.merange;
         W.ikind = j.icost;
-        W.set_mvp(j.mvmin_x, j.mvmin_y, j.qmvp_x, j.qmvp_y);      // setMVP (bitcost.h:43)
+        W.set_mvp(j.qmvp_x, j.qmvp_y);      // setMVP (bitcost.h:43)
         W.stamp(2);
         const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
         const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);

@@ -41,6 +41,8 @@ struct DevBuf
 
 } // namespace
 
+constexpr int EVAL_WORDS = (EVAL_SLOTS + 1) * 16;   // device words behind d_evals
+
 struct x265amd_ctx
 {
     int          device = 0;
@@ -58,7 +60,7 @@ struct x265amd_ctx
     std::vector<float>    bitsizes;       // BitCost::s_bitsizes
     std::vector<uint16_t> h_cost[52];
     uint16_t    *d_cost = nullptr;        // 52 x 65536
-    unsigned long long *d_evals = nullptr;
+    unsigned long long *d_evals = nullptr;   // EVAL_SLOTS counters 16 words apart (+ 16 words of developer counters)
 
     DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
@@ -608,7 +610,7 @@ int x265amd_create(int device, x265amd_ctx **out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->d_planes, sizeof(c->h_planes))) != hipSuccess ||
         (e = hipMalloc(&c->d_cost, (size_t)52 * 65536 * sizeof(uint16_t))) != hipSuccess ||
-        (e = hipMalloc(&c->d_evals, 16 * sizeof(unsigned long long))) != hipSuccess)
+        (e = hipMalloc(&c->d_evals, EVAL_WORDS * sizeof(unsigned long long))) != hipSuccess)
     {
         fprintf(stderr, "x265amd_create: %s\n", hipGetErrorString(e));
         delete c;
@@ -621,7 +623,7 @@ int x265amd_create(int device, x265amd_ctx **out)
             delete c;
             return X265AMD_ERR_HIP;
         }
-    hipMemset(c->d_evals, 0, 16 * sizeof(unsigned long long));
+    hipMemset(c->d_evals, 0, EVAL_WORDS * sizeof(unsigned long long));
     // the exhaustive kernel uses up to 64 KiB of dynamic LDS
     const void *full_kernels[] = { (const void*)k_full_items<0>, (const void*)k_full_items<1>, (const void*)k_full_items<2>,
                                    (const void*)k_full_items<3>, (const void*)k_full_items<4>, (const void*)k_full_items<6>,
@@ -912,20 +914,22 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> t(EVAL_WORDS);
+    HIPCHK(c, hipMemcpy(t.data(), c->d_evals, EVAL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long v = 0;
-    HIPCHK(c, hipMemcpy(&v, c->d_evals, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < EVAL_SLOTS; i++)
+        v += t[(size_t)i * 16];
     if (evals)
         *evals = v;
 #ifdef XA_PROFILE
     {
-        unsigned long long t[16];
-        HIPCHK(c, hipMemcpy(t, c->d_evals, sizeof(t), hipMemcpyDeviceToHost));
+        const unsigned long long *q = &t[(size_t)EVAL_SLOTS * 16];
         fprintf(stderr, "phase clocks: bind %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu\n",
-                t[1], t[2], t[3], t[4], t[5], t[6]);
+                q[0], q[1], q[2], q[3], q[4], q[5]);
     }
 #endif
     if (reset)
-        HIPCHK(c, hipMemset(c->d_evals, 0, 16 * sizeof(v)));
+        HIPCHK(c, hipMemset(c->d_evals, 0, EVAL_WORDS * sizeof(unsigned long long)));
     return 0;
 }
 
