@@ -69,6 +69,13 @@ struct x265amd_ctx
     int    flags = 0;
     bool   timed_full = false, timed_any = false;
     hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+    // Independent kernels of one batch (job classes, exhaustive-kernel size classes) run side by
+    // side on auxiliary streams, so that one launch's tail overlaps the others: fork() makes the
+    // auxiliary streams wait for the main one, join() the reverse.
+    static constexpr int N_AUX = 3;
+    hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
+    hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
+    hipStream_t lane(int k) const { return (k % (N_AUX + 1)) == 0 ? stream : aux[(k % (N_AUX + 1)) - 1]; }
 };
 
 // A planned job list: the jobs live in device memory together with the work-item plan of the
@@ -245,19 +252,37 @@ int record_start(x265amd_ctx *c)
     return 0;
 }
 
+int fork_streams(x265amd_ctx *c, int lanes)
+{
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int i = 0; i < x265amd_ctx::N_AUX && i + 1 < lanes; i++)
+        HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+    return 0;
+}
+int join_streams(x265amd_ctx *c, int lanes)
+{
+    for (int i = 0; i < x265amd_ctx::N_AUX && i + 1 < lanes; i++)
+    {
+        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+    }
+    return 0;
+}
+
 // idx[cls] / cnt[cls]: device index lists of the job classes (idx == NULL: every block looks at its own
 // job and the kernels of the other classes skip it)
 template <typename PIX>
 void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *d_jobs, const int *const *idx, const int *cnt,
-                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out)
+                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool side_by_side)
 {
     // the large PUs first: they are the long-running workgroups
+    int k = 0;
     if (cnt[2] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024>>), dim3(cnt[2]), dim3(512), 0, c->stream, P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256>>), dim3(cnt[1]), dim3(256), 0, c->stream, P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256>>), dim3(cnt[1]), dim3(256), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64>>), dim3(cnt[0]), dim3(64), 0, c->stream, P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
 }
 
 int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
@@ -278,10 +303,16 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
             off += cls_count[k];
         }
     }
+    // with index lists every launch has work: run the classes side by side
+    const int lanes = idx_base ? (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) : 1;
+    if (lanes > 1)
+        if (int rc = fork_streams(c, lanes)) return rc;
     if (bpp == 1)
-        launch_classes<uint8_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out);
+        launch_classes<uint8_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else
-        launch_classes<uint16_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out);
+        launch_classes<uint16_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
+    if (lanes > 1)
+        if (int rc = join_streams(c, lanes)) return rc;
     HIPCHK(c, hipGetLastError());
     if (c->timing)
     {
@@ -546,10 +577,15 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
     if (int rc = record_start(c)) return rc;
+    const int lanes = (int)std::min<size_t>(L->launches.size(), x265amd_ctx::N_AUX + 1);
+    if (lanes > 1)
+        if (int rc = fork_streams(c, lanes)) return rc;
+    int k = 0;
     for (const x265amd_joblist::Launch &la : L->launches)
     {
+        hipStream_t st = c->lane(k++);
 #define XA_LAUNCH_FULL(W4V)                                                                                   \
-        hipLaunchKernelGGL(k_full_items<W4V>, dim3(la.count), dim3(FULL_THREADS), la.lds_bytes, c->stream, P, \
+        hipLaunchKernelGGL(k_full_items<W4V>, dim3(la.count), dim3(FULL_THREADS), la.lds_bytes, st, P,        \
                            (const x265amd_me_job*)L->jobs.p, (const int*)L->item_jobs.p,                      \
                            (const FullItem*)L->items.p + la.first, la.count, (FullBest*)L->fb.p, FB_STRIDE_PLAN, \
                            la.lds_bytes / 4)
@@ -569,6 +605,8 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
         HIPCHK(c, hipGetLastError());
         c->timed_full = true;
     }
+    if (lanes > 1)
+        if (int rc = join_streams(c, lanes)) return rc;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
                           L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
@@ -607,7 +645,15 @@ int x265amd_create(int device, x265amd_ctx **out)
     memset(c->owned, 0, sizeof(c->owned));
     memset(c->base, 0, sizeof(c->base));
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+    e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < x265amd_ctx::N_AUX && e == hipSuccess; i++)
+    {
+        e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->d_planes, sizeof(c->h_planes))) != hipSuccess ||
         (e = hipMalloc(&c->d_cost, (size_t)52 * 65536 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc(&c->d_evals, EVAL_WORDS * sizeof(unsigned long long))) != hipSuccess)
@@ -665,6 +711,12 @@ void x265amd_destroy(x265amd_ctx *c)
     hipFree(c->d_planes);
     hipFree(c->d_cost);
     hipFree(c->d_evals);
+    for (int i = 0; i < x265amd_ctx::N_AUX; i++)
+    {
+        if (c->aux[i]) hipStreamDestroy(c->aux[i]);
+        if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     hipStreamDestroy(c->stream);
     delete c;
 }
