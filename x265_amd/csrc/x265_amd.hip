@@ -473,6 +473,31 @@ void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vecto
     out.push_back(p3);
 }
 
+// Workgroup i of a launch runs on XCD i % 8, and every XCD has its own L2.  Reorder a list that is
+// sorted by picture position so that each XCD works on contiguous bands of it: the list is cut
+// into 8 * XCD_BANDS bands and XCD x takes bands x, x + 8, ... in turn (several bands per XCD even
+// out the lighter work at the picture's top and bottom edges, where search ranges are clipped).
+constexpr int N_XCD = 8, XCD_BANDS = 2;
+bool g_no_xcd_bands = false;       // tuning aid: X265AMD_FLAGS bit 2 keeps picture order
+template <class T>
+void xcd_interleave(std::vector<T> &v)
+{
+    const size_t n = v.size(), per = (n + N_XCD * XCD_BANDS - 1) / (N_XCD * XCD_BANDS);
+    if (n < 4 * N_XCD * XCD_BANDS || g_no_xcd_bands)
+        return;
+    std::vector<T> out;
+    out.reserve(n);
+    for (size_t g = 0; g < (size_t)XCD_BANDS; g++)
+        for (size_t k = 0; k < per; k++)
+            for (size_t x = 0; x < (size_t)N_XCD; x++)
+            {
+                const size_t src = (g * N_XCD + x) * per + k;
+                if (src < n)
+                    out.push_back(v[src]);
+            }
+    v.swap(out);
+}
+
 int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs, int n, int bpp)
 {
     L->n = n;
@@ -485,13 +510,16 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         std::vector<int> order;
         for (int cls = 0; cls < JOB_CLASSES; cls++)
         {
-            L->cls_count[cls] = 0;
+            std::vector<int> seg;
             for (int i = 0; i < n; i++)
                 if (job_class(jobs[i].w, jobs[i].h) == cls)
-                {
-                    order.push_back(i);
-                    L->cls_count[cls]++;
-                }
+                    seg.push_back(i);
+            L->cls_count[cls] = (int)seg.size();
+            std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
+                       std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
+            xcd_interleave(seg);
+            order.insert(order.end(), seg.begin(), seg.end());
         }
         if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
         HIPCHK(c, hipMemcpy(L->idx.p, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
@@ -530,14 +558,6 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         // launch order: widest PUs / largest LDS class first (longest work items start first)
         std::stable_sort(planned.begin(), planned.end(), [&](const PlannedItem &a, const PlannedItem &b) {
             return std::make_pair(w4of(a), cls(a)) > std::make_pair(w4of(b), cls(b)); });
-        std::vector<FullItem> items;
-        std::vector<int> item_jobs;
-        for (PlannedItem &p : planned)
-        {
-            p.it.first = (int)item_jobs.size();
-            item_jobs.insert(item_jobs.end(), p.members.begin(), p.members.end());
-            items.push_back(p.it);
-        }
         for (size_t a = 0; a < planned.size();)
         {
             size_t b = a;
@@ -545,7 +565,21 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
             while (b < planned.size() && cls(planned[b]) == k && w4of(planned[b]) == w4)
                 b++;
             L->launches.push_back({ (int)a, (int)(b - a), k_lds_classes[k] & ~3, w4 });
+            // inside a launch: picture order, dealt to the XCDs in contiguous bands
+            std::vector<PlannedItem> seg(planned.begin() + a, planned.begin() + b);
+            std::stable_sort(seg.begin(), seg.end(), [](const PlannedItem &x, const PlannedItem &y) {
+                return std::make_pair(x.it.win_y0, x.it.win_x0) < std::make_pair(y.it.win_y0, y.it.win_x0); });
+            xcd_interleave(seg);
+            std::copy(seg.begin(), seg.end(), planned.begin() + a);
             a = b;
+        }
+        std::vector<FullItem> items;
+        std::vector<int> item_jobs;
+        for (PlannedItem &p : planned)
+        {
+            p.it.first = (int)item_jobs.size();
+            item_jobs.insert(item_jobs.end(), p.members.begin(), p.members.end());
+            items.push_back(p.it);
         }
         std::vector<FullBest> fb((size_t)n * FB_STRIDE_PLAN);
         for (FullBest &f : fb)
@@ -685,7 +719,10 @@ int x265amd_create(int device, x265amd_ctx **out)
         return X265AMD_ERR_NO_DEVICE;
     }
     if (const char *ev = getenv("X265AMD_FLAGS"))        // tuning aid, see BatchParams::flags
+    {
         c->flags = atoi(ev);
+        g_no_xcd_bands = (c->flags & 4) != 0;
+    }
     *out = c;
     return X265AMD_OK;
 }
