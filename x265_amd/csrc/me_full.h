@@ -151,6 +151,103 @@ __device__ __forceinline__ unsigned long long scan_job(const uint32_t *win, int 
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiny PUs (at most 16 dwords: 8x8, 8x4, 4x8, 4x4, 16x4).  The whole encoder block sits in scalar
+// registers, a lane task is 4 x-candidates x 4 candidate rows (every window dword pair feeds four
+// candidate rows), the row loop is fully unrolled, and no flush is needed (<= 64 pixels per
+// candidate).  The winner is tracked as ONE 32-bit key (cost << 15 | raster index): the cost of a
+// tiny PU is below 2^17 (64 x 255 + 65535) and the caller guarantees nx * ny <= 2^15.
+// Candidates beyond nx / y_hi are switched off by OR-ing all-ones into their key.
+constexpr int TINY_R = 4;
+constexpr int TINY_KEY_SHIFT = 15;
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int W4, int H>
+__device__ __forceinline__ uint32_t scan_tiny(const uint32_t *win, int P, const uint32_t *fe /* H*W4 uniform dwords */,
+                                              const uint16_t *cx, const uint16_t *cy,
+                                              int nx, int y_lo, int y_hi, int id, int stride)
+{
+    constexpr int R = TINY_R;
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1);
+    const int nquads = (y_hi - y_lo + R - 1) / R;
+    const int ntasks = nquads * XGe;
+    uint32_t best = ~0u;
+    for (int task = id; task < ntasks; task += stride)
+    {
+        const int yq = task / XGe, xg = task - yq * XGe;
+        if (xg >= XG)
+            continue;
+        const uint32_t *row = win + (R * yq) * P + xg;
+        unsigned long long p[R];
+#pragma unroll
+        for (int i = 0; i < R; i++)
+            p[i] = 0;
+#pragma unroll
+        for (int r = 0; r < H + R - 1; r++)
+        {
+            unsigned long long d[W4];
+#pragma unroll
+            for (int k = 0; k < W4; k++)
+                d[k] = lds_pair(row + r * P + k);
+#pragma unroll
+            for (int i = 0; i < R; i++)
+            {
+                const int e = r - i;                    // encoder row that window row r meets in candidate row i
+                if (e >= 0 && e < H)
+                {
+#pragma unroll
+                    for (int k = 0; k < W4; k++)
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d[k], fe[e * W4 + k], p[i]);
+                }
+            }
+        }
+        // MV costs of the 4 x-candidates as two packed pairs; per-candidate kill masks OR-ed with x
+        const uint32_t *cxp = (const uint32_t*)(cx + 4 * xg);
+        const uint32_t cx01 = cxp[0], cx23 = cxp[1];
+        const int nvalid = nx - 4 * xg;
+        uint32_t kx[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            kx[x] = (x < nvalid ? 0u : ~0u) | (uint32_t)x;
+        const int y0 = y_lo + R * yq;
+#pragma unroll
+        for (int i = 0; i < R; i++)
+        {
+            const int y = y0 + i;
+            const uint32_t cyv = cy[y < y_hi ? y : y_lo];
+            ushort2v a01, a23, c2 = { (unsigned short)cyv, (unsigned short)cyv };
+            __builtin_memcpy(&a01, &cx01, 4);
+            __builtin_memcpy(&a23, &cx23, 4);
+            a01 += c2;                                  // uint16 wrap-around = the reference's uint16_t mvcost sum
+            a23 += c2;
+            const uint32_t plo = (uint32_t)p[i], phi = (uint32_t)(p[i] >> 32);
+            const uint32_t c0 = (plo & 0xffff) + a01.x, c1 = (plo >> 16) + a01.y;
+            const uint32_t c2v = (phi & 0xffff) + a23.x, c3 = (phi >> 16) + a23.y;
+            uint32_t m = (c0 << 2) | kx[0];
+            uint32_t t1 = (c1 << 2) | kx[1], t2 = (c2v << 2) | kx[2], t3 = (c3 << 2) | kx[3];
+            m = t1 < m ? t1 : m;
+            t2 = t3 < t2 ? t3 : t2;
+            m = t2 < m ? t2 : m;
+            // (cost << 2 | x)  ->  (cost << 15 | y * nx + 4 xg + x)
+            uint32_t key = ((m >> 2) << TINY_KEY_SHIFT) + (uint32_t)(y * nx + 4 * xg) + (m & 3);
+            key = y < y_hi ? key : ~0u;
+            best = key < best ? key : best;
+        }
+    }
+    return best;
+}
+
 __device__ __forceinline__ void write_best(FullBest *out, unsigned long long best, const x265amd_me_job &j, int nx)
 {
     FullBest f;
@@ -242,8 +339,27 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
                 const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
                 const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
                 const uint16_t *cx = (const uint16_t*)(scr + h * W4);
-                unsigned long long b = scan_job<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64);
-                b = wave_min_u64(b);
+                unsigned long long b;
+                if (W4 <= 4 && h * W4 <= 16 && it.win_rows && nx * ny <= (1 << TINY_KEY_SHIFT))
+                {
+                    // tiny PU: encoder block into scalar registers (dword i from lane i)
+                    constexpr int TW4 = W4 <= 4 ? W4 : 1;
+                    const uint32_t mine = scr[lane < h * W4 ? lane : 0];
+                    uint32_t fe[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        fe[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+                    uint32_t b32 = h == 8 ? scan_tiny<TW4, (TW4 <= 2 ? 8 : 4)>(s_win + wy * pitch + wx, pitch, fe, cx, cx + nx, nx, ty0, y_hi, lane, 64)
+                                          : scan_tiny<TW4, 4>(s_win + wy * pitch + wx, pitch, fe, cx, cx + nx, nx, ty0, y_hi, lane, 64);
+                    b32 = wave_min_u32(b32);
+                    b = b32 == ~0u ? ~0ull
+                                   : ((unsigned long long)(b32 >> TINY_KEY_SHIFT) << 32) | (b32 & ((1u << TINY_KEY_SHIFT) - 1));
+                }
+                else
+                {
+                    b = scan_job<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64);
+                    b = wave_min_u64(b);
+                }
                 // a planned wave-mode item covers all candidate rows in one tile
                 if (lane == 0)
                     write_best(fb + (size_t)jid * fb_stride + it.slot, b, j, nx);

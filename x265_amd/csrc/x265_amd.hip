@@ -370,7 +370,8 @@ bool plan_item(const x265amd_me_job *jobs, const std::vector<int> &members, int 
         y0 = std::min(y0, j.pu_y + j.mvmin_y + y_lo);
         int ny = j.mvmax_y - j.mvmin_y + 1;
         int yh = std::min(y_hi, ny);
-        y1 = std::max(y1, j.pu_y + j.mvmin_y + yh + h + 1);
+        // window rows: candidate rows + h - 1, rounded up to the rows a lane task spans (2; 4 for tiny PUs)
+        y1 = std::max(y1, j.pu_y + j.mvmin_y + yh + h + (h * W4 <= 16 ? 3 : 1));
     }
     int nd = 0;
     for (int m : members)
