@@ -22,9 +22,13 @@
 
 namespace xa {
 
+#ifdef XA_PROFILE
+__device__ unsigned long long g_full_prof[8];     // developer aid: clocks {workgroup total, staging, job staging, scan}, items
+#define XA_TICK() ((long long)__builtin_readcyclecounter())
+#endif
 constexpr int FULL_THREADS = 256;
 constexpr int FULL_WAVES = FULL_THREADS / 64;
-constexpr int FB_STRIDE_PLAN = 8;         // FullBest slots per job in a planned job list (max slabs)
+constexpr int FB_STRIDE_PLAN = 16;        // FullBest slots per job in a planned job list (max slabs)
 
 struct FullItem
 {
@@ -307,8 +311,15 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
     const int64_t lo = ref.lo, hi = ref.hi - 4;
 
     unsigned long long blk_best = ~0ull;          // block mode accumulates over tiles
+#ifdef XA_PROFILE
+    const long long t_begin = XA_TICK();
+    long long t_stage = 0, t_job = 0, t_scan = 0;
+#endif
     for (int ty0 = it.y_lo; ty0 < it.y_hi; ty0 += TH)
     {
+#ifdef XA_PROFILE
+        const long long t_a = XA_TICK();
+#endif
         const int ty1 = (it.y_hi - ty0 < TH) ? it.y_hi : ty0 + TH;
         const int rows = it.win_rows ? it.win_rows : (ty1 - ty0) + h - 1 + ((ty1 - ty0) & 1);
         __syncthreads();
@@ -323,6 +334,9 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
             }
         }
         __syncthreads();
+#ifdef XA_PROFILE
+        t_stage += XA_TICK() - t_a;
+#endif
 
         if (wave_mode)
         {
@@ -374,13 +388,23 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
                 const x265amd_me_job &j = jobs[jid];
                 const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
                 __syncthreads();
+#ifdef XA_PROFILE
+                const long long t_b = XA_TICK();
+#endif
                 stage_job<W4>(enc, P.cost[j.qp], j, s_scratch, nx, ny, tid, FULL_THREADS);
                 __syncthreads();
+#ifdef XA_PROFILE
+                const long long t_c = XA_TICK();
+                t_job += t_c - t_b;
+#endif
                 const int y_hi = ty1 < ny ? ty1 : ny;
                 const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
                 const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
                 const uint16_t *cx = (const uint16_t*)(s_scratch + h * W4);
                 unsigned long long b = scan_job<W4>(s_win + wy * pitch + wx, pitch, s_scratch, cx, cx + nx, h, nx, ty0, y_hi, tid, FULL_THREADS);
+#ifdef XA_PROFILE
+                t_scan += XA_TICK() - t_c;
+#endif
                 b = wave_min_u64(b);
                 if (it.count == 1)
                     blk_best = b < blk_best ? b : blk_best;      // reduce across waves after the last tile
@@ -400,6 +424,21 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
             }
         }
     }
+#ifdef XA_PROFILE
+    if (tid == 0 && (blockIdx.x & 15) == 0)
+    {
+        atomicAdd(&g_full_prof[0], (unsigned long long)(XA_TICK() - t_begin));
+        atomicAdd(&g_full_prof[1], (unsigned long long)t_stage);
+        atomicAdd(&g_full_prof[2], (unsigned long long)t_job);
+        atomicAdd(&g_full_prof[3], (unsigned long long)t_scan);
+        atomicAdd(&g_full_prof[4], 1ull);
+    }
+    if (tid == 0)
+    {
+        atomicMin(&g_full_prof[5], (unsigned long long)t_begin);
+        atomicMax(&g_full_prof[6], (unsigned long long)XA_TICK());
+    }
+#endif
     if (!wave_mode && it.count == 1)
     {
         const int jid = item_jobs[it.first];

@@ -419,52 +419,46 @@ void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vecto
         return;
     }
     // single job: cut into row slabs.  A slab of p candidate-row pairs is p * XGe lane tasks, executed
-    // in ceil(p * XGe / 256) passes of the workgroup: pick the slab count that wastes the fewest
-    // pass slots, preferring more (smaller) items when the waste is equal, as long as an item
-    // keeps a reasonable amount of work.
+    // in ceil(p * XGe / 256) passes of the workgroup.  Slabs are sized to fill k whole passes
+    // (p = floor(256 k / XGe)), the remainder goes to the last slab; k is the smallest that keeps
+    // a reasonable amount of work per item and at most FB_STRIDE_PLAN slabs.  Short items of
+    // whole passes keep both the pass slots and the last round of workgroups on the GPU full.
     const x265amd_me_job &j = jobs[members[0]];
     const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     const int xg = (nx + 3) >> 2, xge = xg + (xg & 1);
     const int pairs_total = (ny + 1) >> 1;
-    const double work = (double)nx * ny * j.w * j.h;
-    int best_s = 1;
-    long best_passes = -1;
-    for (int sl = 1; sl <= FB_STRIDE_PLAN && sl <= pairs_total; sl++)
+    int p_first = pairs_total;
+    for (int k = 1; k <= 64; k++)
     {
-        if (sl > 1 && work / sl < PLAN_SLAB_WORK / 4)
+        const int p = std::max(1, FULL_THREADS * k / xge);
+        if (p >= pairs_total)
+            break;                                   // one slab
+        const double slab_work = 2.0 * p * nx * j.w * j.h;
+        if (slab_work >= PLAN_SLAB_WORK / 4 && (pairs_total + p - 1) / p <= FB_STRIDE_PLAN)
+        {
+            p_first = p;
             break;
-        long passes = 0;
-        for (int k = 0; k < sl; k++)
-        {
-            int pk = pairs_total / sl + (k < pairs_total % sl ? 1 : 0);
-            passes += ((long)pk * xge + FULL_THREADS - 1) / FULL_THREADS;
-        }
-        if (best_passes < 0 || passes <= best_passes)
-        {
-            best_passes = passes;
-            best_s = sl;
         }
     }
-    for (int slabs = best_s; slabs <= FB_STRIDE_PLAN; slabs++)
-    {
+    auto try_plan = [&](int p) {
         std::vector<PlannedItem> tmp;
-        bool ok = true;
         int y = 0;
-        for (int k = 0; k < slabs && ok; k++)
+        for (int k = 0; y < ny; k++)
         {
-            int pk = pairs_total / slabs + (k < pairs_total % slabs ? 1 : 0);
-            int y1 = std::min(ny, y + 2 * pk);
+            int y1 = std::min(ny, y + 2 * p);
             PlannedItem p2;
-            ok = plan_item(jobs, members, y, y1, k, p2);
+            if (!plan_item(jobs, members, y, y1, k, p2))
+                return false;
             tmp.push_back(p2);
             y = y1;
         }
-        if (ok)
-        {
-            out.insert(out.end(), tmp.begin(), tmp.end());
+        out.insert(out.end(), tmp.begin(), tmp.end());
+        return true;
+    };
+    // (if a slab's window does not fit the LDS, thinner slabs need fewer rows)
+    for (int p = p_first; p >= 1 && (pairs_total + p - 1) / p <= FB_STRIDE_PLAN; p--)
+        if (try_plan(p))
             return;
-        }
-    }
     // does not fit even as FB_STRIDE_PLAN slabs: one item, tiled inside the kernel (win_rows = 0)
     PlannedItem p3;
     plan_item(jobs, members, 0, ny, 0, p3);
@@ -1016,6 +1010,14 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
         const unsigned long long *q = &t[(size_t)EVAL_SLOTS * 16];
         fprintf(stderr, "phase clocks: bind %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu\n",
                 q[0], q[1], q[2], q[3], q[4], q[5]);
+        unsigned long long fp[8], zero[8] = { 0, 0, 0, 0, 0, ~0ull, 0, 0 };
+        HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_full_prof), sizeof(fp)));
+        if (fp[4])
+            fprintf(stderr, "exhaustive (sampled wave 0 of %llu items): total %llu  window staging %llu  job staging %llu  scan %llu clocks per item\n",
+                    fp[4], fp[0] / fp[4], fp[1] / fp[4], fp[2] / fp[4], fp[3] / fp[4]);
+        if (fp[6] > fp[5] && fp[5] != ~0ull)
+            fprintf(stderr, "exhaustive kernels spanned %llu shader clocks (first workgroup start to last end, all launches since the last read)\n", fp[6] - fp[5]);
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_full_prof), zero, sizeof(zero)));
     }
 #endif
     if (reset)
