@@ -120,6 +120,13 @@ class Engine:
     def stream(self) -> int:
         return self.lib.x265amd_stream(self.h)
 
+    def torch_stream(self):
+        """The engine's HIP stream as a torch stream object (for GPU-side ordering against torch work)."""
+        import torch
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = torch.cuda.ExternalStream(self.stream, device=torch.device("cuda", self.device))
+        return self._tstream
+
     def sync(self):
         self._chk(self.lib.x265amd_sync(self.h))
 

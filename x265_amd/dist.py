@@ -36,13 +36,18 @@ def broadcast_plane(plane: torch.Tensor, src: int = 0, engine=None) -> torch.Ten
     """Broadcast a padded reference plane (uint8/uint16 tensor, same shape on every rank) from
     `src` to all ranks, in place.  One collective per plane: the planes are small (2.6 MB at
     1080p, 9.3 MB at 4K) and xGMI is point-to-point, so a single direct fan-out beats any
-    per-row or ring schedule.  If `engine` is given the call also orders the copy before work
-    queued afterwards on the engine's own HIP stream."""
+    per-row or ring schedule.  If `engine` is given, the copy is ordered on the GPU (events, no
+    host wait) after the searches already queued on the engine's own HIP stream - they may still
+    read the plane - and before the work queued on it afterwards."""
+    ordered = engine is not None and plane.is_cuda and world() > 1     # (alone, nothing is copied)
+    if ordered:
+        cur = torch.cuda.current_stream(plane.device)
+        ext = engine.torch_stream()
+        cur.wait_stream(ext)
     if world() > 1:
         dist.broadcast(plane, src=src)
-    if engine is not None and plane.is_cuda:
-        # the search kernels run on the engine's stream, the collective on torch's current stream
-        torch.cuda.current_stream(plane.device).synchronize()
+    if ordered:
+        ext.wait_stream(cur)
     return plane
 
 
