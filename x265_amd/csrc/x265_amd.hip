@@ -287,9 +287,9 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
 
 int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
                    const int *idx_base, const int *cls_count,
-                   const FullBest *fb, int fb_stride, x265amd_me_result *d_out)
+                   const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool timing_events = true)
 {
-    if (c->timing)
+    if (c->timing && timing_events)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr };
     int cnt[JOB_CLASSES] = { n, n, n };
@@ -314,7 +314,7 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
     if (lanes > 1)
         if (int rc = join_streams(c, lanes)) return rc;
     HIPCHK(c, hipGetLastError());
-    if (c->timing)
+    if (c->timing && timing_events)
     {
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
         c->timed_any = true;
@@ -603,9 +603,9 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
     delete L;
 }
 
-int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
+// the exhaustive-kernel launches of a planned list
+int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
-    if (int rc = record_start(c)) return rc;
     const int lanes = (int)std::min<size_t>(L->launches.size(), x265amd_ctx::N_AUX + 1);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
@@ -632,15 +632,29 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
         }
 #undef XA_LAUNCH_FULL
         HIPCHK(c, hipGetLastError());
-        c->timed_full = true;
     }
     if (lanes > 1)
         if (int rc = join_streams(c, lanes)) return rc;
+    return 0;
+}
+
+// the general-kernel launches of a planned list
+int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P, bool timing_events)
+{
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
                           L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
-                          (x265amd_me_result*)L->results.p);
+                          (x265amd_me_result*)L->results.p, timing_events);
 }
+
+int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
+{
+    if (int rc = record_start(c)) return rc;
+    if (int rc = joblist_launch_full(c, L, P)) return rc;
+    c->timed_full = !L->launches.empty();
+    return joblist_launch_search(c, L, P, true);
+}
+
 
 } // namespace
 
