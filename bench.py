@@ -48,7 +48,7 @@ def build_job_lists():
     return hex_jobs, full_jobs
 
 
-def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=10.0):
+def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=20.0):
     """Time the CPU path on the host cores for a bounded sample of the same workloads.
     kind 'reference' = the reference's own C path (oracle/_ref, compiled from the reference's
     sources), 1 thread; falls back to kind 'port' (oracle/libme_oracle.so) if it is absent."""
@@ -91,7 +91,7 @@ def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=10.0):
     out["hex"] = {"value": hex_evals * reps / dt, "unit": "evals/s", "cores": 1, "kind": kind,
                   "sample": "%d of %d jobs of the HEX+subme5 frame (every 2nd), %d repetitions, %.1f s" % (len(hs), len(hex_jobs), reps, dt)}
     # FULL workload: ~0.15 s per 64x64 PU on one core -> a strided sample of PUs of all four sizes
-    fs = np.concatenate([full_jobs[full_jobs["w"] == s][:: st] for s, st in ((64, 24), (32, 50), (16, 100), (8, 200))])
+    fs = np.concatenate([full_jobs[full_jobs["w"] == s][:: st] for s, st in ((64, 3), (32, 6), (16, 12), (8, 24))])
     d, res = time_ref(fs) if kind == "reference" else time_port(fs, 1)[:2]
     fe = J.full_search_evals(fs)
     px = float((J.full_search_evals(fs[fs["w"] == 64]) * 4096 + J.full_search_evals(fs[fs["w"] == 32]) * 1024 +
@@ -192,6 +192,31 @@ def main():
     alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
     achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
 
+    # ---- the same frame with the diamond search (the other method BASELINE configs[1] names) ----
+    dia_jobs = hex_jobs.copy()
+    dia_jobs["method"] = J.DIA
+    jl_dia = eng.make_joblist(dia_jobs)
+    ddt, devals, _, k_dia_ms = timed(jl_dia, 2, args.steps)
+    jl_dia.close()
+
+    # ---- PCIe-inclusive: both planes uploaded and the MV/cost field downloaded every frame -------
+    enc_pin = torch.from_numpy(enc_np).pin_memory()
+    ref_pin = torch.from_numpy(ref_np).pin_memory()
+    def pcie_step():
+        enc_t.copy_(enc_pin, non_blocking=True)
+        if rank == 0:
+            ref_t.copy_(ref_pin, non_blocking=True)
+        eng.torch_stream().wait_stream(torch.cuda.current_stream(dev))
+        return jl_hex.run(enc_id, [ref_id], fetch=True)        # blocks until the results are on the host
+    for _ in range(2):
+        pcie_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pcie_step()
+    barrier()
+    pcie_dt = time.perf_counter() - t0
+
     # ---- secondary: FULL +-64 (configs[0] on the GPU) --------------------------------------
     fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, 2, args.full_steps)
     full_res = jl_full.run(enc_id, [ref_id], fetch=True)
@@ -233,10 +258,19 @@ def main():
         "config": {"workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 hpel + 8 qpel SATD), PUs 16x16+64x64 "
                                "(BASELINE configs[1]); one frame per GPU per step; reference plane broadcast from rank 0",
                    "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": evals / (args.steps * world),
+                   # subme 5 = 1 + 8 + 8 SATD evaluations per PU (encoder/motion.cpp:57); the rest are SADs
+                   "satd_evals_per_frame": 17 * int(len(hex_jobs)),
+                   "sad_evals_per_frame": evals / (args.steps * world) - 17 * int(len(hex_jobs)),
                    "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world},
         "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "dia_search": {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
+                       "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms},
+        "pcie_inclusive": {"workload": "HEX+subme5 frame; enc and ref planes copied host->device and the MV/cost field "
+                                       "device->host every frame, frames not overlapped",
+                           "frames_per_s": world * args.steps / pcie_dt, "ms_per_frame": pcie_dt / args.steps * 1e3,
+                           "value": evals / args.steps / world * (world * args.steps / pcie_dt), "unit": "evals/s"},
         "full_search": {"workload": "1080p 8-bit, FULL +-64 SAD, PUs 64/32/16/8, subme 0 (BASELINE configs[0] on the GPU)",
                         "value": fevals / fdt, "unit": "evals/s", "frames_per_s": world * args.full_steps / fdt,
                         "ms_per_frame": fdt / args.full_steps * 1e3, "jobs_per_frame": int(len(full_jobs)),
