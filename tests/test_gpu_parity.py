@@ -196,6 +196,36 @@ def test_full_search_properties_at_full_size(eng, oracle):
         eng.release_plane(i)
 
 
+def test_exhaustive_ties_and_wide_ranges(eng, oracle):
+    """FULL search where every candidate has the same SAD (flat and periodic pictures: the winner is
+    decided by the MV cost and, on equal cost, by raster order) and with ranges wide enough
+    (201 x 201 candidates) to leave the small-PU fast path of the exhaustive kernel."""
+    W, H = 640, 480
+    flat = np.full((H, W), 77, dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    periodic = (((xx // 4) + (yy // 4)) % 2 * 90 + 40).astype(np.uint8)      # 8-pixel period: many exact ties
+    for img in (flat, periodic):
+        enc = synth.pad_plane(img)
+        ref = synth.pad_plane(img)
+        ids = [eng.upload_plane(enc), eng.upload_plane(ref)]
+        parts = []
+        for (w, h, mr, qmvp) in ((8, 8, 64, (0, 0)), (8, 8, 100, (9, -14)), (4, 8, 100, (0, 0)), (16, 16, 64, (-21, 6)),
+                                 (16, 8, 100, (3, 3)), (32, 32, 64, (0, 0)), (64, 64, 64, (13, 2))):
+            x, y = J.square_pu_grid(W, H, max(w, h))
+            sel = slice(None, None, max(1, len(x) // 40))
+            parts.append(J.make_jobs(W, H, x[sel], y[sel], w, h, method=J.FULL, subme=0, merange=mr, qp=30, qmvp=qmvp))
+        jobs = np.concatenate(parts)
+        exp, _ = oracle.search(enc, [ref], jobs, threads=8)
+        got = eng.search(ids[0], [ids[1]], jobs)
+        assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:5]
+        jl = eng.make_joblist(jobs)
+        got2 = jl.run(ids[0], [ids[1]])
+        jl.close()
+        assert np.array_equal(got2, exp), np.nonzero(got2 != exp)[0][:5]
+        for i in ids:
+            eng.release_plane(i)
+
+
 def test_device_resident_and_planned_paths_agree(eng, oracle):
     """The three ways in (host batch, raw device job array, planned job list) give identical,
     oracle-exact results; the job list mixes FULL jobs of every size class with pattern searches."""

@@ -194,6 +194,9 @@ int check_plane_args(x265amd_ctx *c, int width, int height, int margin_x, int ma
     if (width <= 0 || height <= 0 || margin_x < 0 || margin_y < 0 || stride < width + 2 * margin_x ||
         (bpp != 1 && bpp != 2) || depth < 8 || depth > 8 * bpp || depth > 14)
         return fail(c, X265AMD_ERR_INVALID, "bad plane geometry");
+    // the kernels address pixels with 32-bit element offsets relative to a block inside the plane
+    if ((int64_t)(height + 2 * margin_y) * (int64_t)stride >= (int64_t)1 << 30)
+        return fail(c, X265AMD_ERR_INVALID, "plane too large (2^30 elements or more)");
     return 0;
 }
 
