@@ -105,6 +105,11 @@ def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=20.0):
     return out
 
 
+def trace(msg):
+    if os.environ.get("X265AMD_BENCH_TRACE"):
+        print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,14 +127,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    # (rehearsals of the N > 1 path on a one-GPU box: X265AMD_DIST_BACKEND=gloo puts every rank on that GPU)
+    backend = os.environ.get("X265AMD_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
+    trace("process group up")
     from x265_amd.api import Engine
     eng = Engine(local_rank)
+    trace("engine created")
 
     # ---- inputs, resident in HBM ---------------------------------------------------------
     base = synth.base_frame(W, H)
@@ -137,21 +150,34 @@ def main():
     enc_np = synth.pad_plane(synth.moved_frame(base, rank + 1))     # this rank's current frame
     stride = ref_np.shape[1]
     enc_t = torch.from_numpy(enc_np).to(dev)
-    ref_t = torch.from_numpy(ref_np).to(dev) if rank == 0 else torch.zeros(ref_np.shape, dtype=torch.uint8, device=dev)
+    # two reference buffers: the broadcast for the next step overlaps the current step's search
+    ref_bufs = [torch.from_numpy(ref_np).to(dev) if rank == 0 else torch.zeros(ref_np.shape, dtype=torch.uint8, device=dev)
+                for _ in range(2)]
+    ref_t = ref_bufs[0]
     enc_id = eng.wrap_device_plane(enc_t.data_ptr(), W, H, stride, 1, 8)
-    ref_id = eng.wrap_device_plane(ref_t.data_ptr(), W, H, stride, 1, 8)
+    ref_ids = [eng.wrap_device_plane(t.data_ptr(), W, H, stride, 1, 8) for t in ref_bufs]
+    ref_id = ref_ids[0]
 
     hex_jobs, full_jobs = build_job_lists()
     # planned job lists: jobs, work-item plan and result buffers live in device memory
     jl_hex = eng.make_joblist(hex_jobs)
     jl_full = eng.make_joblist(full_jobs)
     eng.set_timing(True)
-
+    trace("job lists planned")
     from x265_amd import dist as xd
 
+    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=bool(os.environ.get("X265AMD_OVERLAP_BROADCAST")))
+    step_no = [0]
+
     def step(jl):
-        xd.broadcast_plane(ref_t, src=0, engine=eng)   # reference plane: rank 0 -> all (RCCL over xGMI when N > 1)
-        jl.run(enc_id, [ref_id], fetch=False)
+        # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame
+        k = step_no[0]
+        step_no[0] += 1
+        b = ring.acquire(k)
+        trace("step %d: reference in buffer %d" % (k, b))
+        jl.run(enc_id, [ref_ids[b]], fetch=False)
+        ring.prefetch(k + 1)
+        ring.release(k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -163,15 +189,18 @@ def main():
         """K steps queued back to back (no host wait inside the timed region); kernel times of the last step."""
         for _ in range(warmup):
             step(jl)
+        trace("warm-up queued")
         eng.sync()
         eng.eval_count(reset=True)
         barrier()
+        trace("timed region starts")
         t0 = time.perf_counter()
         for _ in range(steps):
             step(jl)
         eng.sync()
         barrier()
         dt = time.perf_counter() - t0
+        trace("timed region done")
         k_full, k_search = eng.kernel_times()     # HIP events on the engine's streams around the last step's kernels
         evals = eng.eval_count()
         if world > 1:

@@ -35,6 +35,19 @@ def _worker(rank, world, port, q):
     ref = torch.from_numpy(frames[0].copy()) if rank == 0 else torch.zeros(frames[0].shape, dtype=torch.uint8)
     xd.broadcast_plane(ref, src=0)
     assert np.array_equal(ref.numpy(), frames[0])
+    # a ring of two buffers: plane k is broadcast while plane k - 1 is in use
+    bufs = [torch.zeros(frames[0].shape, dtype=torch.uint8) for _ in range(2)]
+    ring = xd.PlaneRing(bufs, src=0, overlap=True)
+    for k in range(4):
+        if rank == 0 and ring.ready < k:
+            bufs[ring.slot(k)].copy_(torch.from_numpy(frames[k]))
+        b = ring.acquire(k)
+        assert b == k % 2 and np.array_equal(bufs[b].numpy(), frames[k]), k
+        if rank == 0:
+            bufs[ring.slot(k + 1)].copy_(torch.from_numpy(frames[k + 1]))
+        ring.prefetch(k + 1)
+        assert np.array_equal(bufs[b].numpy(), frames[k]), k       # the buffer in use is untouched
+        ring.release(k)
     mine = xd.shard_frames(NFRAMES, rank, world)
     o = Oracle()
     local = [o.search(frames[f + 1], [ref.numpy()], jobs)[0] for f in mine]

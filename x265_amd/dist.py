@@ -36,19 +36,67 @@ def broadcast_plane(plane: torch.Tensor, src: int = 0, engine=None) -> torch.Ten
     """Broadcast a padded reference plane (uint8/uint16 tensor, same shape on every rank) from
     `src` to all ranks, in place.  One collective per plane: the planes are small (2.6 MB at
     1080p, 9.3 MB at 4K) and xGMI is point-to-point, so a single direct fan-out beats any
-    per-row or ring schedule.  If `engine` is given, the copy is ordered on the GPU (events, no
-    host wait) after the searches already queued on the engine's own HIP stream - they may still
-    read the plane - and before the work queued on it afterwards."""
+    per-row or ring schedule.  If `engine` is given, the call first waits for the searches queued
+    on the engine's stream (they may still read the plane) and returns when the copy is complete,
+    so work queued on the engine afterwards sees the new plane.  (PlaneRing overlaps the two.)"""
     ordered = engine is not None and plane.is_cuda and world() > 1     # (alone, nothing is copied)
     if ordered:
-        cur = torch.cuda.current_stream(plane.device)
-        ext = engine.torch_stream()
-        cur.wait_stream(ext)
+        engine.sync()
     if world() > 1:
         dist.broadcast(plane, src=src)
     if ordered:
-        ext.wait_stream(cur)
+        torch.cuda.current_stream(plane.device).synchronize()
     return plane
+
+
+class PlaneRing:
+    """Reference planes arriving one per frame, each broadcast from its owner into one of two
+    buffers.  Per frame k the caller runs
+        b = ring.acquire(k)        # buffer holding plane k (broadcast by prefetch(k), or now)
+        ... queue the search of frame k on the engine, reading buffer b ...
+        ring.prefetch(k + 1)       # overlap=True only: start the next broadcast into the other buffer
+        ring.release(k)            # wait for the search of frame k (and for the prefetch)
+    Every hand-over is a host-side wait: no stream ever waits on another stream's events.
+    With a single rank nothing is copied and nothing waits (searches simply queue up).
+
+    overlap=False (the default) keeps the collective and the search kernels strictly one after the
+    other.  Overlapping them (prefetch) is implemented but off: a two-rank rehearsal on one GPU
+    (gloo backend, both ranks sharing the device) stopped making progress after some tens of
+    steps whenever a broadcast ran beside the search kernels, and ran clean with the two
+    serialised; until the overlapped form has run on a real multi-GPU node it is not the default."""
+
+    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = False):
+        assert len(buffers) == 2
+        self.buffers = list(buffers)
+        self.engine = engine
+        self.src = src
+        self.overlap = overlap
+        self.gpu = engine is not None and self.buffers[0].is_cuda
+        self.ready = -1                     # index of the newest plane already broadcast
+
+    def slot(self, k: int) -> int:
+        return k & 1
+
+    def _broadcast(self, k: int) -> None:
+        dist.broadcast(self.buffers[self.slot(k)], src=self.src)
+        self.ready = k
+
+    def acquire(self, k: int) -> int:
+        if world() > 1 and self.ready < k:
+            self._broadcast(k)
+            if self.gpu:
+                torch.cuda.current_stream(self.buffers[0].device).synchronize()
+        return self.slot(k)
+
+    def prefetch(self, k: int) -> None:
+        if self.overlap and world() > 1 and self.ready < k:
+            self._broadcast(k)
+
+    def release(self, k: int) -> None:
+        if world() > 1 and self.gpu:
+            self.engine.sync()
+            if self.overlap:
+                torch.cuda.current_stream(self.buffers[0].device).synchronize()
 
 
 def gather_results(local: np.ndarray, frames: Sequence[int], n_frames: int, dst: int = 0, device=None):
