@@ -313,6 +313,7 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
     unsigned long long blk_best = ~0ull;          // block mode accumulates over tiles
 #ifdef XA_PROFILE
     const long long t_begin = XA_TICK();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();      // constant 100 MHz counter
     long long t_stage = 0, t_job = 0, t_scan = 0;
 #endif
     for (int ty0 = it.y_lo; ty0 < it.y_hi; ty0 += TH)
@@ -432,12 +433,9 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
         atomicAdd(&g_full_prof[2], (unsigned long long)t_job);
         atomicAdd(&g_full_prof[3], (unsigned long long)t_scan);
         atomicAdd(&g_full_prof[4], 1ull);
+        atomicAdd(&g_full_prof[7], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - r_begin));
     }
-    if (tid == 0)
-    {
-        atomicMin(&g_full_prof[5], (unsigned long long)t_begin);
-        atomicMax(&g_full_prof[6], (unsigned long long)XA_TICK());
-    }
+
 #endif
     if (!wave_mode && it.count == 1)
     {

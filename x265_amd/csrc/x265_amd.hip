@@ -1027,13 +1027,12 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
         const unsigned long long *q = &t[(size_t)EVAL_SLOTS * 16];
         fprintf(stderr, "phase clocks: bind %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu\n",
                 q[0], q[1], q[2], q[3], q[4], q[5]);
-        unsigned long long fp[8], zero[8] = { 0, 0, 0, 0, 0, ~0ull, 0, 0 };
+        unsigned long long fp[8], zero[8] = { 0 };
         HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_full_prof), sizeof(fp)));
         if (fp[4])
-            fprintf(stderr, "exhaustive (sampled wave 0 of %llu items): total %llu  window staging %llu  job staging %llu  scan %llu clocks per item\n",
-                    fp[4], fp[0] / fp[4], fp[1] / fp[4], fp[2] / fp[4], fp[3] / fp[4]);
-        if (fp[6] > fp[5] && fp[5] != ~0ull)
-            fprintf(stderr, "exhaustive kernels spanned %llu shader clocks (first workgroup start to last end, all launches since the last read)\n", fp[6] - fp[5]);
+            fprintf(stderr, "exhaustive (sampled wave 0 of %llu items): total %llu  window staging %llu  job staging %llu  scan %llu clocks per item; %.2f us per item by the 100 MHz counter -> the clock counter runs at %.0f MHz\n",
+                    fp[4], fp[0] / fp[4], fp[1] / fp[4], fp[2] / fp[4], fp[3] / fp[4], fp[7] / (double)fp[4] / 100.0,
+                    fp[7] ? fp[0] / (fp[7] / 100.0) : 0.0);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_full_prof), zero, sizeof(zero)));
     }
 #endif
