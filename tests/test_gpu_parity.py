@@ -196,29 +196,37 @@ def test_full_search_properties_at_full_size(eng, oracle):
         eng.release_plane(i)
 
 
-def test_exhaustive_ties_and_wide_ranges(eng, oracle):
+@pytest.mark.parametrize("bits", [8, 16])
+def test_exhaustive_ties_and_wide_ranges(eng, oracle, bits):
     """FULL search where every candidate has the same SAD (flat and periodic pictures: the winner is
-    decided by the MV cost and, on equal cost, by raster order) and with ranges wide enough
-    (201 x 201 candidates) to leave the small-PU fast path of the exhaustive kernel."""
+    decided by the MV cost and, on equal cost, by raster order), with ranges wide enough
+    (201 x 201 candidates) to leave the small-PU fast path of the 8-bit exhaustive kernel, and on a
+    moving textured picture at +-64; 8-bit and 10-bit-in-16-bit planes."""
     W, H = 640, 480
-    flat = np.full((H, W), 77, dtype=np.uint8)
+    depth = 8 if bits == 8 else 10
+    dt = np.uint8 if bits == 8 else np.uint16
+    scale = 1 if bits == 8 else 4
+    flat = np.full((H, W), 77 * scale, dtype=dt)
     yy, xx = np.mgrid[0:H, 0:W]
-    periodic = (((xx // 4) + (yy // 4)) % 2 * 90 + 40).astype(np.uint8)      # 8-pixel period: many exact ties
-    for img in (flat, periodic):
-        enc = synth.pad_plane(img)
-        ref = synth.pad_plane(img)
-        ids = [eng.upload_plane(enc), eng.upload_plane(ref)]
+    periodic = ((((xx // 4) + (yy // 4)) % 2 * 90 + 40) * scale).astype(dt)      # 8-pixel period: many exact ties
+    seq = synth.make_sequence(W, H, 2, seed=17, bit_depth=depth)
+    cases = [(synth.pad_plane(flat, depth), synth.pad_plane(flat, depth)),
+             (synth.pad_plane(periodic, depth), synth.pad_plane(periodic, depth)),
+             (seq[1], seq[0])]
+    for enc, ref in cases:
+        ids = [eng.upload_plane(enc, bit_depth=depth), eng.upload_plane(ref, bit_depth=depth)]
         parts = []
         for (w, h, mr, qmvp) in ((8, 8, 64, (0, 0)), (8, 8, 100, (9, -14)), (4, 8, 100, (0, 0)), (16, 16, 64, (-21, 6)),
-                                 (16, 8, 100, (3, 3)), (32, 32, 64, (0, 0)), (64, 64, 64, (13, 2))):
+                                 (16, 8, 100, (3, 3)), (32, 32, 64, (0, 0)), (64, 64, 64, (13, 2)), (24, 32, 64, (0, 0)),
+                                 (48, 64, 33, (-7, 7)), (12, 16, 20, (0, 0))):
             x, y = J.square_pu_grid(W, H, max(w, h))
-            sel = slice(None, None, max(1, len(x) // 40))
+            sel = slice(None, None, max(1, len(x) // 24))
             parts.append(J.make_jobs(W, H, x[sel], y[sel], w, h, method=J.FULL, subme=0, merange=mr, qp=30, qmvp=qmvp))
         jobs = np.concatenate(parts)
-        exp, _ = oracle.search(enc, [ref], jobs, threads=8)
+        exp, _ = oracle.search(enc, [ref], jobs, threads=8, bit_depth=depth)
         got = eng.search(ids[0], [ids[1]], jobs)
         assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:5]
-        jl = eng.make_joblist(jobs)
+        jl = eng.make_joblist(jobs, bytes_per_px=bits // 8)
         got2 = jl.run(ids[0], [ids[1]])
         jl.close()
         assert np.array_equal(got2, exp), np.nonzero(got2 != exp)[0][:5]

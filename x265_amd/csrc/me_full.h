@@ -1,4 +1,6 @@
-// Exhaustive (FULL_SEARCH) integer stage for 8-bit planes, driven by WORK ITEMS.
+// Exhaustive (FULL_SEARCH) integer stage (SAD metric), driven by WORK ITEMS.  The description below
+// is the 8-bit form; 16-bit planes use the same items, windows and lane tasks with two pixels per
+// dword and v_sad_u16 (scan_job16).
 //
 // A work item is a set of jobs whose search windows overlap (PUs of one size inside one cell of
 // the picture) plus a range of candidate rows.  One 256-thread workgroup executes one item:
@@ -252,6 +254,103 @@ __device__ __forceinline__ uint32_t scan_tiny(const uint32_t *win, int P, const 
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit pixels: a dword holds 2 pixels, there is no byte-shifted packed SAD, so the lane keeps
+// each window dword d[i] and its one-pixel-shifted neighbour o[i] = (d[i+1]:d[i]) >> 16 and
+// issues v_sad_u16 (2 pixels per lane-op): candidate x uses d[k], o[k], d[k+1], o[k+1] against
+// encoder dword k.  Same lane task (4 x-candidates x 2 candidate rows), same item / window /
+// winner-key scheme as the 8-bit scan; the row is processed in chunks of 8 dwords to bound
+// registers.  `win` / `P` / `fenc` are in dwords; W4 = PU width / 4 (2 * W4 dwords per row).
+template <int W4>
+__device__ __forceinline__ unsigned long long scan_job16(const uint32_t *win, int P, const uint32_t *fenc,
+                                                         const uint16_t *cx, const uint16_t *cy,
+                                                         int h, int nx, int y_lo, int y_hi, int id, int stride)
+{
+    constexpr int W2 = 2 * W4;                    // dwords per encoder row
+    constexpr int CH = W2 % 8 == 0 ? 8 : W2 % 6 == 0 ? 6 : W2 % 4 == 0 ? 4 : 2;     // dwords per chunk (divides W2)
+    const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1);
+    const int npairs = (y_hi - y_lo + 1) >> 1;
+    const int ntasks = npairs * XGe;
+    unsigned long long best = ~0ull;
+
+    for (int task = id; task < ntasks; task += stride)
+    {
+        const int yp = task / XGe, xg = task - yp * XGe;
+        if (xg >= XG)
+            continue;
+        const uint32_t *row = win + (2 * yp) * P + 2 * xg;
+        uint32_t sa[4] = { 0, 0, 0, 0 }, sb[4] = { 0, 0, 0, 0 };
+        // window row r meets encoder row r in candidate row A and encoder row r - 1 in candidate row B
+        for (int r = 0; r <= h; r++)
+        {
+            const uint32_t *wr = row + r * P;
+            const uint32_t *fa = fenc + (r < h ? r : 0) * W2, *fb = fenc + (r > 0 ? r - 1 : 0) * W2;
+            const bool doA = r < h, doB = r > 0;
+#pragma unroll
+            for (int c0 = 0; c0 < W2; c0 += CH)
+            {
+                uint32_t d[CH + 2], o[CH + 1];
+#pragma unroll
+                for (int i = 0; i < CH + 2; i += 2)
+                {
+                    const unsigned long long v = lds_pair(wr + c0 + i);
+                    d[i] = (uint32_t)v;
+                    d[i + 1] = (uint32_t)(v >> 32);
+                }
+#pragma unroll
+                for (int i = 0; i <= CH; i++)
+                    o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2);
+                if (doA)
+                {
+#pragma unroll
+                    for (int i = 0; i < CH; i++)
+                    {
+                        const uint32_t f = fa[c0 + i];
+                        sa[0] = __builtin_amdgcn_sad_u16(d[i], f, sa[0]);
+                        sa[1] = __builtin_amdgcn_sad_u16(o[i], f, sa[1]);
+                        sa[2] = __builtin_amdgcn_sad_u16(d[i + 1], f, sa[2]);
+                        sa[3] = __builtin_amdgcn_sad_u16(o[i + 1], f, sa[3]);
+                    }
+                }
+                if (doB)
+                {
+#pragma unroll
+                    for (int i = 0; i < CH; i++)
+                    {
+                        const uint32_t f = fb[c0 + i];
+                        sb[0] = __builtin_amdgcn_sad_u16(d[i], f, sb[0]);
+                        sb[1] = __builtin_amdgcn_sad_u16(o[i], f, sb[1]);
+                        sb[2] = __builtin_amdgcn_sad_u16(d[i + 1], f, sb[2]);
+                        sb[3] = __builtin_amdgcn_sad_u16(o[i + 1], f, sb[3]);
+                    }
+                }
+            }
+        }
+        const int iy = y_lo + 2 * yp;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+        {
+            const int y = iy + rr;
+            if (y < y_hi)
+            {
+                const int cyv = cy[y];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int x = 4 * xg + i;
+                    if (x < nx)
+                    {
+                        uint32_t c = (rr ? sb[i] : sa[i]) + (uint32_t)((cx[x] + cyv) & 0xffff);
+                        unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(y * nx + x);
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+    return best;
+}
+
 __device__ __forceinline__ void write_best(FullBest *out, unsigned long long best, const x265amd_me_job &j, int nx)
 {
     FullBest f;
@@ -270,26 +369,30 @@ __device__ __forceinline__ void write_best(FullBest *out, unsigned long long bes
     *out = f;
 }
 
-// stage one job's encoder block and MV-cost slices into `scratch` (layout: fenc[h*W4] | cx[nx] | cy[ny] as u16)
-template <int W4>
+// stage one job's encoder block and MV-cost slices into `scratch`
+// (layout: fenc[h * W4 * sizeof(PIX)] dwords | cx[nx] | cy[ny] as u16)
+template <int W4, typename PIX>
 __device__ __forceinline__ void stage_job(const PlaneDesc &enc, const uint16_t *cost, const x265amd_me_job &j,
                                           uint32_t *scratch, int nx, int ny, int id, int stride)
 {
+    constexpr int RD = W4 * (int)sizeof(PIX);         // dwords per encoder row
     const int h = j.h;
-    const uint8_t *e = (const uint8_t*)enc.origin + (int64_t)j.pu_y * enc.stride + j.pu_x;
-    for (int i = id; i < h * W4; i += stride)
-        scratch[i] = ld_u32(e + (int64_t)(i / W4) * enc.stride + 4 * (i % W4));
-    uint16_t *cx = (uint16_t*)(scratch + h * W4), *cy = cx + nx;
+    const PIX *e = (const PIX*)enc.origin + (int64_t)j.pu_y * enc.stride + j.pu_x;
+    for (int i = id; i < h * RD; i += stride)
+        scratch[i] = ld_u32((const uint8_t*)(e + (int64_t)(i / RD) * enc.stride) + 4 * (i % RD));
+    uint16_t *cx = (uint16_t*)(scratch + h * RD), *cy = cx + nx;
     for (int i = id; i < nx; i += stride)
         cx[i] = cost[(int16_t)((int16_t)((j.mvmin_x + i) << 2) - j.qmvp_x)];
     for (int i = id; i < ny; i += stride)
         cy[i] = cost[(int16_t)((int16_t)((j.mvmin_y + i) << 2) - j.qmvp_y)];
 }
 
-template <int W4>
+template <int W4, typename PIX>
 __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs, const int *item_jobs,
                                const FullItem &it, FullBest *fb, int fb_stride, uint32_t *lds, int lds_dwords)
 {
+    constexpr int PB = (int)sizeof(PIX);          // bytes per pixel = dwords per 4 pixels
+    constexpr int PPD = 4 / PB;                   // pixels per dword
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
@@ -299,7 +402,7 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
     const bool wave_mode = it.count >= FULL_WAVES;
 
     // scratch: per wave (wave mode) or one for the block
-    const int scratch_dw = h * W4 + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
+    const int scratch_dw = h * W4 * PB + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
     const int n_scratch = wave_mode ? FULL_WAVES : 1;
     uint32_t *s_scratch = lds;
     uint32_t *s_win = lds + n_scratch * scratch_dw;
@@ -308,7 +411,7 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
     if (TH < 2)
         return;                                   // cannot happen for planned items
     const uint8_t *r0 = (const uint8_t*)ref.origin;
-    const int64_t lo = ref.lo, hi = ref.hi - 4;
+    const int64_t lo = ref.lo, hi = ref.hi - PPD;     // element offsets a staged dword may start at
 
     unsigned long long blk_best = ~0ull;          // block mode accumulates over tiles
 #ifdef XA_PROFILE
@@ -329,9 +432,9 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
             int64_t o = (int64_t)(it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo) + r) * ref.stride + it.win_x0;
             for (int c = lane; c < ND; c += 64)
             {
-                int64_t a = o + 4 * c;
+                int64_t a = o + PPD * c;
                 a = a < lo ? lo : (a > hi ? hi : a);
-                s_win[r * pitch + c] = ld_u32(r0 + a);
+                s_win[r * pitch + c] = ld_u32(r0 + a * PB);
             }
         }
         __syncthreads();
@@ -347,15 +450,15 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
                 const int jid = item_jobs[it.first + m];
                 const x265amd_me_job &j = jobs[jid];
                 const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-                stage_job<W4>(enc, P.cost[j.qp], j, scr, nx, ny, lane, 64);
+                stage_job<W4, PIX>(enc, P.cost[j.qp], j, scr, nx, ny, lane, 64);
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const int y_hi = ty1 < ny ? ty1 : ny;
-                const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
+                const int wx = ((j.pu_x + j.mvmin_x - it.win_x0) >> 2) * PB;
                 const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
-                const uint16_t *cx = (const uint16_t*)(scr + h * W4);
+                const uint16_t *cx = (const uint16_t*)(scr + h * W4 * PB);
                 unsigned long long b;
-                if (W4 <= 4 && h * W4 <= 16 && it.win_rows && nx * ny <= (1 << TINY_KEY_SHIFT))
+                if (PB == 1 && W4 <= 4 && h * W4 <= 16 && it.win_rows && nx * ny <= (1 << TINY_KEY_SHIFT))
                 {
                     // tiny PU: encoder block into scalar registers (dword i from lane i)
                     constexpr int TW4 = W4 <= 4 ? W4 : 1;
@@ -372,7 +475,8 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
                 }
                 else
                 {
-                    b = scan_job<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64);
+                    b = PB == 1 ? scan_job<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64)
+                                : scan_job16<W4>(s_win + wy * pitch + wx, pitch, scr, cx, cx + nx, h, nx, ty0, y_hi, lane, 64);
                     b = wave_min_u64(b);
                 }
                 // a planned wave-mode item covers all candidate rows in one tile
@@ -392,17 +496,19 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
 #ifdef XA_PROFILE
                 const long long t_b = XA_TICK();
 #endif
-                stage_job<W4>(enc, P.cost[j.qp], j, s_scratch, nx, ny, tid, FULL_THREADS);
+                stage_job<W4, PIX>(enc, P.cost[j.qp], j, s_scratch, nx, ny, tid, FULL_THREADS);
                 __syncthreads();
 #ifdef XA_PROFILE
                 const long long t_c = XA_TICK();
                 t_job += t_c - t_b;
 #endif
                 const int y_hi = ty1 < ny ? ty1 : ny;
-                const int wx = (j.pu_x + j.mvmin_x - it.win_x0) >> 2;
+                const int wx = ((j.pu_x + j.mvmin_x - it.win_x0) >> 2) * PB;
                 const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
-                const uint16_t *cx = (const uint16_t*)(s_scratch + h * W4);
-                unsigned long long b = scan_job<W4>(s_win + wy * pitch + wx, pitch, s_scratch, cx, cx + nx, h, nx, ty0, y_hi, tid, FULL_THREADS);
+                const uint16_t *cx = (const uint16_t*)(s_scratch + h * W4 * PB);
+                unsigned long long b = PB == 1
+                    ? scan_job<W4>(s_win + wy * pitch + wx, pitch, s_scratch, cx, cx + nx, h, nx, ty0, y_hi, tid, FULL_THREADS)
+                    : scan_job16<W4>(s_win + wy * pitch + wx, pitch, s_scratch, cx, cx + nx, h, nx, ty0, y_hi, tid, FULL_THREADS);
 #ifdef XA_PROFILE
                 t_scan += XA_TICK() - t_c;
 #endif
@@ -456,7 +562,7 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
 
 // One instantiation per PU width so that narrow PUs keep a small register footprint (occupancy).
 // W4 = 0 selects by the item's job width at run time (unplanned path).
-template <int W4>
+template <int W4, typename PIX>
 __global__ void __launch_bounds__(FULL_THREADS) k_full_items(BatchParams P, const x265amd_me_job *jobs,
                                                              const int *item_jobs, const FullItem *items, int n_items,
                                                              FullBest *fb, int fb_stride, int lds_dwords)
@@ -470,20 +576,20 @@ __global__ void __launch_bounds__(FULL_THREADS) k_full_items(BatchParams P, cons
         return;
     if (W4 != 0)
     {
-        full_item_body<W4 ? W4 : 1>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords);
+        full_item_body<W4 ? W4 : 1, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords);
         return;
     }
     const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
     switch (j0.w >> 2)
     {
-    case 1:  full_item_body<1>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 2:  full_item_body<2>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 3:  full_item_body<3>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 4:  full_item_body<4>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 6:  full_item_body<6>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 8:  full_item_body<8>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 12: full_item_body<12>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 16: full_item_body<16>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 1:  full_item_body<1, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 2:  full_item_body<2, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 3:  full_item_body<3, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 4:  full_item_body<4, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 6:  full_item_body<6, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 8:  full_item_body<8, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 12: full_item_body<12, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+    case 16: full_item_body<16, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
     default: break;
     }
 }
@@ -502,7 +608,7 @@ __global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, i
     it.count = full_kernel_eligible(j, P.planes[P.enc_plane].bpp) ? 1 : 0;
     const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1), W4 = j.w >> 2;
-    const int ND = XGe + W4;
+    const int ND = (XGe + W4) * P.planes[P.enc_plane].bpp;      // dwords per window row
     it.y_lo = 0;
     it.y_hi = ny;
     it.slot = 0;
@@ -510,7 +616,7 @@ __global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, i
     it.win_y0 = j.pu_y + j.mvmin_y;
     it.win_rows = 0;                               // staged per tile
     it.win_nd = ND;
-    it.pitch = ND + ((((XGe >> 1) - ND) % 16) + 16) % 16;
+    it.pitch = P.planes[P.enc_plane].bpp == 1 ? ND + ((((XGe >> 1) - ND) % 16) + 16) % 16 : ND + 2;
     items[id] = it;
 }
 

@@ -18,12 +18,12 @@ struct BatchParams
     int32_t          flags;               // JF_* bits applied to every job (tuning aids)
 };
 
-// Does the dedicated exhaustive kernel handle this job?  (8-bit pixels, SAD metric, bounded range)
+// Does the dedicated exhaustive kernel handle this job?  (SAD metric, bounded range)
 template <class J>
 __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
 {
     int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-    return j.method == X265AMD_FULL && j.icost == X265AMD_SAD && bpp == 1 &&
+    return j.method == X265AMD_FULL && j.icost == X265AMD_SAD && (bpp == 1 || bpp == 2) &&
            nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
 }
 

@@ -331,7 +331,6 @@ int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const
 {
     FullBest *fb = nullptr;
     if (int rc = record_start(c)) return rc;
-    if (bpp == 1)
     {
         if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
         if (int rc = ensure(c, c->items, (size_t)n * sizeof(FullItem))) return rc;
@@ -339,8 +338,12 @@ int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const
         fb = (FullBest*)c->fullbest.p;
         hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n,
                            (int*)c->item_jobs.p, (FullItem*)c->items.p);
-        hipLaunchKernelGGL(k_full_items<0>, dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
-                           (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
+        if (bpp == 1)
+            hipLaunchKernelGGL((k_full_items<0, uint8_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+                               (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
+        else
+            hipLaunchKernelGGL((k_full_items<0, uint16_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+                               (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
         HIPCHK(c, hipGetLastError());
         c->timed_full = true;
     }
@@ -361,7 +364,7 @@ int pitch_for(int nd, int xge)
 struct PlannedItem { FullItem it; std::vector<int> members; int lds_bytes; };
 
 // window geometry + LDS need of an item holding `members` (indices into jobs) for rows [y_lo,y_hi)
-bool plan_item(const x265amd_me_job *jobs, const std::vector<int> &members, int y_lo, int y_hi, int slot, PlannedItem &out)
+bool plan_item(const x265amd_me_job *jobs, int bpp, const std::vector<int> &members, int y_lo, int y_hi, int slot, PlannedItem &out)
 {
     const x265amd_me_job &j0 = jobs[members[0]];
     const int W4 = j0.w >> 2, h = j0.h;
@@ -374,14 +377,14 @@ bool plan_item(const x265amd_me_job *jobs, const std::vector<int> &members, int 
         int ny = j.mvmax_y - j.mvmin_y + 1;
         int yh = std::min(y_hi, ny);
         // window rows: candidate rows + h - 1, rounded up to the rows a lane task spans (2; 4 for tiny PUs)
-        y1 = std::max(y1, j.pu_y + j.mvmin_y + yh + h + (h * W4 <= 16 ? 3 : 1));
+        y1 = std::max(y1, j.pu_y + j.mvmin_y + yh + h + (bpp == 1 && h * W4 <= 16 ? 3 : 1));
     }
     int nd = 0;
     for (int m : members)
     {
         const x265amd_me_job &j = jobs[m];
         int nx = j.mvmax_x - j.mvmin_x + 1, xg = (nx + 3) >> 2, xge = xg + (xg & 1);
-        nd = std::max(nd, ((j.pu_x + j.mvmin_x - x0) >> 2) + xge + W4);
+        nd = std::max(nd, (((j.pu_x + j.mvmin_x - x0) >> 2) + xge + W4) * bpp);      // dwords: 4 / bpp pixels each
     }
     const int nx0 = j0.mvmax_x - j0.mvmin_x + 1, xg0 = (nx0 + 3) >> 2, xge0 = xg0 + (xg0 & 1);
     FullItem &it = out.it;
@@ -394,22 +397,22 @@ bool plan_item(const x265amd_me_job *jobs, const std::vector<int> &members, int 
     it.win_y0 = y0;
     it.win_rows = y1 - y0;
     it.win_nd = nd;
-    it.pitch = pitch_for(nd, xge0);
-    const int scratch_dw = h * W4 + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
+    it.pitch = bpp == 1 ? pitch_for(nd, xge0) : nd + 2;
+    const int scratch_dw = h * W4 * bpp + ((2 * FULL_MAX_CAND + 1) >> 1) + 1;
     const int n_scratch = it.count >= FULL_WAVES ? FULL_WAVES : 1;
     out.lds_bytes = 4 * (n_scratch * scratch_dw + it.win_rows * it.pitch);
     out.members = members;
     return out.lds_bytes <= FULL_LDS_MAX;
 }
 
-void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vector<PlannedItem> &out)
+void plan_group(const x265amd_me_job *jobs, int bpp, std::vector<int> members, std::vector<PlannedItem> &out)
 {
     // a shared-window item must cover all candidate rows of its jobs in one staging pass
     int nymax = 0;
     for (int m : members)
         nymax = std::max(nymax, jobs[m].mvmax_y - jobs[m].mvmin_y + 1);
     PlannedItem pi;
-    if (members.size() > 1 && plan_item(jobs, members, 0, nymax, 0, pi) && pi.lds_bytes <= k_lds_classes[2])
+    if (members.size() > 1 && plan_item(jobs, bpp, members, 0, nymax, 0, pi) && pi.lds_bytes <= k_lds_classes[2])
     {
         out.push_back(pi);
         return;
@@ -417,8 +420,8 @@ void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vecto
     if (members.size() > 1)
     {
         size_t half = members.size() / 2;
-        plan_group(jobs, std::vector<int>(members.begin(), members.begin() + half), out);
-        plan_group(jobs, std::vector<int>(members.begin() + half, members.end()), out);
+        plan_group(jobs, bpp, std::vector<int>(members.begin(), members.begin() + half), out);
+        plan_group(jobs, bpp, std::vector<int>(members.begin() + half, members.end()), out);
         return;
     }
     // single job: cut into row slabs.  A slab of p candidate-row pairs is p * XGe lane tasks, executed
@@ -450,7 +453,7 @@ void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vecto
         {
             int y1 = std::min(ny, y + 2 * p);
             PlannedItem p2;
-            if (!plan_item(jobs, members, y, y1, k, p2))
+            if (!plan_item(jobs, bpp, members, y, y1, k, p2))
                 return false;
             tmp.push_back(p2);
             y = y1;
@@ -464,7 +467,7 @@ void plan_group(const x265amd_me_job *jobs, std::vector<int> members, std::vecto
             return;
     // does not fit even as FB_STRIDE_PLAN slabs: one item, tiled inside the kernel (win_rows = 0)
     PlannedItem p3;
-    plan_item(jobs, members, 0, ny, 0, p3);
+    plan_item(jobs, bpp, members, 0, ny, 0, p3);
     p3.it.win_rows = 0;
     p3.it.win_y0 = j.pu_y + j.mvmin_y;
     p3.lds_bytes = FULL_LDS_MAX;
@@ -523,7 +526,6 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         HIPCHK(c, hipMemcpy(L->idx.p, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<PlannedItem> planned;
-    if (bpp == 1)
     {
         std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
         for (int i = 0; i < n; i++)
@@ -538,10 +540,10 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
                                        (j.pu_x + j.mvmin_x) & 3, 0)].push_back(i);
             }
             else
-                plan_group(jobs, std::vector<int>(1, i), planned);
+                plan_group(jobs, bpp, std::vector<int>(1, i), planned);
         }
         for (auto &g : groups)
-            plan_group(jobs, g.second, planned);
+            plan_group(jobs, bpp, g.second, planned);
     }
     if (!planned.empty())
     {
@@ -616,11 +618,12 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
     for (const x265amd_joblist::Launch &la : L->launches)
     {
         hipStream_t st = c->lane(k++);
-#define XA_LAUNCH_FULL(W4V)                                                                                   \
-        hipLaunchKernelGGL(k_full_items<W4V>, dim3(la.count), dim3(FULL_THREADS), la.lds_bytes, st, P,        \
+#define XA_LAUNCH_FULL_PIX(W4V, PIX)                                                                          \
+        hipLaunchKernelGGL((k_full_items<W4V, PIX>), dim3(la.count), dim3(FULL_THREADS), la.lds_bytes, st, P, \
                            (const x265amd_me_job*)L->jobs.p, (const int*)L->item_jobs.p,                      \
                            (const FullItem*)L->items.p + la.first, la.count, (FullBest*)L->fb.p, FB_STRIDE_PLAN, \
                            la.lds_bytes / 4)
+#define XA_LAUNCH_FULL(W4V) do { if (L->bpp == 1) XA_LAUNCH_FULL_PIX(W4V, uint8_t); else XA_LAUNCH_FULL_PIX(W4V, uint16_t); } while (0)
         switch (la.w4)
         {
         case 1:  XA_LAUNCH_FULL(1); break;
@@ -634,6 +637,7 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
         default: XA_LAUNCH_FULL(0); break;
         }
 #undef XA_LAUNCH_FULL
+#undef XA_LAUNCH_FULL_PIX
         HIPCHK(c, hipGetLastError());
     }
     if (lanes > 1)
@@ -717,9 +721,11 @@ int x265amd_create(int device, x265amd_ctx **out)
         }
     hipMemset(c->d_evals, 0, EVAL_WORDS * sizeof(unsigned long long));
     // the exhaustive kernel uses up to 64 KiB of dynamic LDS
-    const void *full_kernels[] = { (const void*)k_full_items<0>, (const void*)k_full_items<1>, (const void*)k_full_items<2>,
-                                   (const void*)k_full_items<3>, (const void*)k_full_items<4>, (const void*)k_full_items<6>,
-                                   (const void*)k_full_items<8>, (const void*)k_full_items<12>, (const void*)k_full_items<16> };
+#define XA_FULL_KERNELS(PIX) (const void*)k_full_items<0, PIX>, (const void*)k_full_items<1, PIX>, (const void*)k_full_items<2, PIX>, \
+                             (const void*)k_full_items<3, PIX>, (const void*)k_full_items<4, PIX>, (const void*)k_full_items<6, PIX>, \
+                             (const void*)k_full_items<8, PIX>, (const void*)k_full_items<12, PIX>, (const void*)k_full_items<16, PIX>
+    const void *full_kernels[] = { XA_FULL_KERNELS(uint8_t), XA_FULL_KERNELS(uint16_t) };
+#undef XA_FULL_KERNELS
     e = hipSuccess;
     for (const void *k : full_kernels)
         if (e == hipSuccess)
