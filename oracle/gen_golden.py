@@ -50,6 +50,8 @@ def main():
             out["res_" + kind] = ref.search(fr[0], [fr[1], fr[2]], jobs)
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "search_u%d.npz" % bits), **out)
         print("bits", bits, "search jobs", len(jobs))
+        # lookahead path: half-resolution planes, isLowres searches, neighbour-predicted MV fields
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "lowres_u%d.npz" % bits), **G.run_lowres_suite(ref, bits))
     ref = Reference(8)
     tabs = {}
     for qp in G.MV_QPS:

@@ -134,19 +134,24 @@ int meo_bitcost(int mvpx, int mvpy, int mvx, int mvy)
 void meo_lowres_core_u8(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                         intptr_t src_stride, intptr_t dst_stride, int width, int height)
 {
-#define AVG4(a, b, c, d) (uint8_t)(((((a) + (b) + 1) >> 1) + (((c) + (d) + 1) >> 1) + 1) >> 1)
-    for (int y = 0; y < height; y++)
-    {
-        const uint8_t *r0 = src0 + 2 * y * src_stride, *r1 = r0 + src_stride, *r2 = r1 + src_stride;
-        for (int x = 0; x < width; x++)
-        {
-            dst0[y * dst_stride + x] = AVG4(r0[2 * x], r1[2 * x], r0[2 * x + 1], r1[2 * x + 1]);
-            dsth[y * dst_stride + x] = AVG4(r0[2 * x + 1], r1[2 * x + 1], r0[2 * x + 2], r1[2 * x + 2]);
-            dstv[y * dst_stride + x] = AVG4(r1[2 * x], r2[2 * x], r1[2 * x + 1], r2[2 * x + 1]);
-            dstc[y * dst_stride + x] = AVG4(r1[2 * x + 1], r2[2 * x + 1], r1[2 * x + 2], r2[2 * x + 2]);
-        }
-    }
-#undef AVG4
+    lowres_core_u8(src0, dst0, dsth, dstv, dstc, src_stride, dst_stride, width, height);
+}
+
+void meo_lowres_init(const void *src, intptr_t src_stride, int bytes_per_px, void *const dst[4], intptr_t dst_stride,
+                     int width, int lines, int mx, int my)
+{
+    if (bytes_per_px == 1)
+        lowres_init_u8((const uint8_t*)src, src_stride, (uint8_t *const*)dst, dst_stride, width, lines, mx, my);
+    else
+        lowres_init_u16((const uint16_t*)src, src_stride, (uint16_t *const*)dst, dst_stride, width, lines, mx, my);
+}
+
+int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, int cuh, int merange,
+                         int method, int subme, int qp, meo_result *out)
+{
+    cost_table_for_qp(qp);
+    return enc->bytes_per_px == 1 ? lookahead_me_u8(enc, ref, cuw, cuh, merange, method, subme, qp, out)
+                                  : lookahead_me_u16(enc, ref, cuw, cuh, merange, method, subme, qp, out);
 }
 
 int64_t meo_search_batch(const meo_plane *enc, const meo_plane *refs, const meo_job *jobs, int n,

@@ -87,6 +87,18 @@ void meo_ipfilter_u16(int kind, const void *src, intptr_t srcStride, void *dst, 
 void meo_lowres_core_u8(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                         intptr_t src_stride, intptr_t dst_stride, int width, int height);
 
+/* Lowres::init, picture part (common/lowres.cpp:175-185): the four half-resolution planes of a
+ * border-replicated source plane (`src` at pixel (0,0)), borders extended by (mx,my);
+ * dst[k] point at pixel (0,0) of the F, H, V, C planes */
+void meo_lowres_init(const void *src, intptr_t src_stride, int bytes_per_px, void *const dst[4], intptr_t dst_stride,
+                     int width, int lines, int mx, int my);
+
+/* motion-search part of Lookahead::estimateFrameCost for one list (encoder/slicetype.cpp:306-316,
+ * 346-407): cuw x cuh 8x8 CUs in reverse raster order with the neighbour-MV predictor chain;
+ * enc / ref carry lowres[] planes.  out[cux + cuy*cuw]; returns the number of block-cost evaluations */
+int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, int cuh, int merange,
+                         int method, int subme, int qp, meo_result *out);
+
 /* run n jobs (one enc plane, jobs[i].ref_idx selects refs[]) with `threads` OpenMP threads
  * (one search state per thread); returns total number of block-cost evaluations. */
 int64_t meo_search_batch(const meo_plane *enc, const meo_plane *refs, const meo_job *jobs, int n,

@@ -920,3 +920,132 @@ static void SUF(bind)(SUF(state) *st, const meo_plane *enc, const meo_plane *ref
     st->cost = cost_table_for_qp(qp);
     st->evals = 0;
 }
+
+/* ---------------------------------------------------------------- lookahead (half-resolution) path */
+
+/* frame_init_lowres_core (common/pixel.cpp:614-637): the four half-resolution planes
+ * F (full-pel), H, V, C (half-pel shifted) from 2x2 / shifted 2x2 neighbourhoods */
+static void SUF(lowres_core)(const PIX *src0, PIX *dst0, PIX *dsth, PIX *dstv, PIX *dstc,
+                             intptr_t src_stride, intptr_t dst_stride, int width, int height)
+{
+#define AVG4(a, b, c, d) (PIX)(((((a) + (b) + 1) >> 1) + (((c) + (d) + 1) >> 1) + 1) >> 1)
+    for (int y = 0; y < height; y++)
+    {
+        const PIX *r0 = src0 + 2 * y * src_stride, *r1 = r0 + src_stride, *r2 = r1 + src_stride;
+        for (int x = 0; x < width; x++)
+        {
+            dst0[y * dst_stride + x] = AVG4(r0[2 * x], r1[2 * x], r0[2 * x + 1], r1[2 * x + 1]);
+            dsth[y * dst_stride + x] = AVG4(r0[2 * x + 1], r1[2 * x + 1], r0[2 * x + 2], r1[2 * x + 2]);
+            dstv[y * dst_stride + x] = AVG4(r1[2 * x], r2[2 * x], r1[2 * x + 1], r2[2 * x + 1]);
+            dstc[y * dst_stride + x] = AVG4(r1[2 * x + 1], r2[2 * x + 1], r1[2 * x + 2], r2[2 * x + 2]);
+        }
+    }
+#undef AVG4
+}
+
+/* TComPicYuv::xExtendPicCompBorder (Lib/TLibCommon/TComPicYuv.cpp:259-286) */
+static void SUF(extend_border)(PIX *p, intptr_t stride, int width, int height, int mx, int my)
+{
+    for (int y = 0; y < height; y++)
+    {
+        PIX *row = p + y * stride;
+        for (int x = 0; x < mx; x++)
+        {
+            row[-mx + x] = row[0];
+            row[width + x] = row[width - 1];
+        }
+    }
+    const size_t bytes = sizeof(PIX) * (size_t)(width + 2 * mx);
+    for (int y = 0; y < my; y++)
+    {
+        memcpy(p + (height + y) * stride - mx, p + (height - 1) * stride - mx, bytes);
+        memcpy(p - (y + 1) * stride - mx, p - mx, bytes);
+    }
+}
+
+/* Lowres::init, picture part (common/lowres.cpp:175-185): downscale, then extend the borders of
+ * all four planes.  `src` points at pixel (0,0) of a plane whose margins hold replicated borders
+ * (the reference extends the source by 7 columns / 2*lines - height rows itself, lowres.cpp:139-173,
+ * and its core then reads one column and one row further still). */
+static void SUF(lowres_init)(const PIX *src, intptr_t src_stride, PIX *const dst[4], intptr_t dst_stride,
+                             int width, int lines, int mx, int my)
+{
+    SUF(lowres_core)(src, dst[0], dst[1], dst[2], dst[3], src_stride, dst_stride, width, lines);
+    for (int k = 0; k < 4; k++)
+        SUF(extend_border)(dst[k], dst_stride, width, lines, mx, my);
+}
+
+/* median() of encoder/slicetype.cpp:48-57, including its 16-bit intermediate (which only matters for
+ * components more than 32767 apart, beyond any picture size) */
+static inline int SUF(median3)(int a, int b, int c)
+{
+    int t = (int16_t)(a - b < 0 ? a - b : 0);
+    a = (int16_t)(a - t);                               /* max(a, b) */
+    b = (int16_t)(b + t);                               /* min(a, b) */
+    b = (int16_t)(b - (b - c < 0 ? b - c : 0));         /* max(min(a, b), c) */
+    b = (int16_t)(b + (a - b < 0 ? a - b : 0));         /* min of the two */
+    return b;
+}
+
+/* The motion-search part of Lookahead::estimateFrameCost / estimateCUCost for one reference list
+ * (encoder/slicetype.cpp:306-316, 346-369, 381-407): 8x8 CUs of the half-resolution picture in
+ * reverse raster order, each predicted from its already searched right / lower neighbours.
+ * out[cux + cuy * cuw] = (lowresMvs, lowresMvCosts) of that CU. */
+static int64_t SUF(lookahead_me)(const meo_plane *enc, const meo_plane *ref, int cuw, int cuh, int merange,
+                                 int method, int subme, int qp, meo_result *out)
+{
+    SUF(state) *st = (SUF(state)*)malloc(sizeof(SUF(state)));
+    int64_t evals = 0;
+    for (int cuy = cuh - 1; cuy >= 0; cuy--)
+    {
+        for (int cux = cuw - 1; cux >= 0; cux--)
+        {
+            const int xy = cux + cuy * cuw;
+            meo_job j;
+            memset(&j, 0, sizeof(j));
+            j.pu_x = 8 * cux;
+            j.pu_y = 8 * cuy;
+            j.w = j.h = 8;
+            /* slicetype.cpp:366-369 */
+            j.mvmin_x = (int16_t)(uint16_t)(-cux * 8 - 8);
+            j.mvmin_y = (int16_t)(uint16_t)(-cuy * 8 - 8);
+            j.mvmax_x = (int16_t)(uint16_t)((cuw - cux - 1) * 8 + 8);
+            j.mvmax_y = (int16_t)(uint16_t)((cuh - cuy - 1) * 8 + 8);
+            j.merange = (int16_t)merange;
+            j.method = (uint8_t)method;
+            j.subme = (uint8_t)subme;
+            j.qp = (uint8_t)qp;
+            /* slicetype.cpp:385-405: candidates right, below, below-left, below-right; mvc[0] and
+             * mvc[2] start as zero vectors */
+            int numc = 0;
+#define ADD_MVC(k) do { j.mvc[numc][0] = out[k].mvx; j.mvc[numc][1] = out[k].mvy; numc++; } while (0)
+            if (cux < cuw - 1)
+                ADD_MVC(xy + 1);
+            if (cuy < cuh - 1)
+            {
+                ADD_MVC(xy + cuw);
+                if (cux > 0)
+                    ADD_MVC(xy + cuw - 1);
+                if (cux < cuw - 1)
+                    ADD_MVC(xy + cuw + 1);
+            }
+#undef ADD_MVC
+            j.numc = (uint8_t)numc;
+            if (numc <= 1)
+            {
+                j.qmvp_x = j.mvc[0][0];
+                j.qmvp_y = j.mvc[0][1];
+            }
+            else
+            {
+                j.qmvp_x = (int16_t)SUF(median3)(j.mvc[0][0], j.mvc[1][0], j.mvc[2][0]);
+                j.qmvp_y = (int16_t)SUF(median3)(j.mvc[0][1], j.mvc[1][1], j.mvc[2][1]);
+            }
+            SUF(bind)(st, enc, ref, j.pu_x, j.pu_y, 8, 8, qp);
+            out[xy].cost = SUF(search)(st, &j, &out[xy].mvx, &out[xy].mvy);
+            evals += st->evals;
+        }
+    }
+    free(st);
+    return evals;
+}

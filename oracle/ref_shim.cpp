@@ -211,6 +211,71 @@ void ref_me_search_batch(void *h, pixel *enc, intptr_t encStride, pixel *ref, in
                                     j[i].merange, j[i].method, j[i].subme, j[i].qp, out_mv + 2 * i);
 }
 
+/* Driver for the lookahead's motion search over one half-resolution frame: the loop order, search
+ * bounds and neighbour candidates of Lookahead::estimateFrameCost / estimateCUCost
+ * (encoder/slicetype.cpp:306-316, 361-407) around the reference's own MotionEstimate.
+ * (slicetype.cpp itself needs the whole encoder to link; only its ME calls are replayed here.)
+ * enc_planes / ref_planes: F,H,V,C plane pointers at pixel (0,0). */
+static inline int16_t shim_median(int16_t a, int16_t b, int16_t c)
+{
+    int16_t lo = a < b ? a : b, hi = a < b ? b : a;
+    int16_t m = hi < c ? hi : c;
+    return lo > m ? lo : m;
+}
+
+void ref_lookahead_me(void *h, pixel **enc_planes, pixel **ref_planes, intptr_t stride, int cuw, int cuh,
+                      int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost)
+{
+    RefME *r = (RefME*)h;
+    r->me.setQP(qp);
+    r->me.setSearchMethod(method);
+    r->me.setSubpelRefine(subme);
+    r->me.setSourcePlane(enc_planes[0], stride);
+    r->planes.fpelPlane = ref_planes[0];
+    r->planes.lumaStride = (int)stride;
+    r->planes.isLowres = true;
+    for (int i = 0; i < 4; i++)
+        r->planes.lowresPlane[i] = ref_planes[i];
+    MV *mvs = new MV[cuw * cuh];
+    for (int cuy = cuh - 1; cuy >= 0; cuy--)
+    {
+        for (int cux = cuw - 1; cux >= 0; cux--)
+        {
+            const int xy = cux + cuy * cuw;
+            r->me.setSourcePU(8 * cux + 8 * cuy * (int)stride, 8, 8);
+            MV mvmin, mvmax, mvc[4], mvp;
+            mvmin.x = (uint16_t)(-cux * 8 - 8);
+            mvmin.y = (uint16_t)(-cuy * 8 - 8);
+            mvmax.x = (uint16_t)((cuw - cux - 1) * 8 + 8);
+            mvmax.y = (uint16_t)((cuh - cuy - 1) * 8 + 8);
+            int numc = 0;
+            mvc[0] = 0;
+            mvc[2] = 0;
+            if (cux < cuw - 1)
+                mvc[numc++] = mvs[xy + 1];
+            if (cuy < cuh - 1)
+            {
+                mvc[numc++] = mvs[xy + cuw];
+                if (cux > 0)
+                    mvc[numc++] = mvs[xy + cuw - 1];
+                if (cux < cuw - 1)
+                    mvc[numc++] = mvs[xy + cuw + 1];
+            }
+            if (numc <= 1)
+                mvp = mvc[0];
+            else
+            {
+                mvp.x = shim_median(mvc[0].x, mvc[1].x, mvc[2].x);
+                mvp.y = shim_median(mvc[0].y, mvc[1].y, mvc[2].y);
+            }
+            out_cost[xy] = r->me.motionEstimate(&r->planes, mvmin, mvmax, mvp, numc, mvc, merange, mvs[xy]);
+            out_mv[2 * xy] = mvs[xy].x;
+            out_mv[2 * xy + 1] = mvs[xy].y;
+        }
+    }
+    delete[] mvs;
+}
+
 /* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */
 int ref_me_buf(void *h, int kind, pixel *enc, intptr_t encStride, int puOffset, int w, int hgt,
                pixel *fref, intptr_t stride)

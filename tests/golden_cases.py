@@ -113,6 +113,59 @@ def field_jobs() -> np.ndarray:
     return J.frame_jobs(FIELD_W, FIELD_H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=32)
 
 
+# lookahead (half-resolution) path
+LOWRES_W, LOWRES_H = 364, 214          # halves to 182 x 107: neither a multiple of 8, stride rounds up to 32
+LOOKAHEAD_CONFIGS = ((1, 1, 16, 12), (0, 2, 16, 12), (3, 3, 8, 22), (2, 5, 16, 12), (4, 1, 4, 30))  # method, subme, merange, qp
+
+
+def lowres_source_frames(bits: int):
+    """full-resolution frames whose half-resolution planes the suites use"""
+    return synth.make_sequence(LOWRES_W, LOWRES_H, 2, seed=555 + bits, bit_depth=8 if bits == 8 else 10, kind="motion")
+
+
+def lowres_jobs(geom, bits: int) -> np.ndarray:
+    """independent jobs on half-resolution planes: every method and sub-pel level, mostly 8x8 (the
+    lookahead's CU) plus other shapes, sub-pel predictors and candidates"""
+    rng = np.random.default_rng(5000 + bits)
+    W, H = geom.width, geom.lines
+    out = []
+    for method in range(5):
+        for subme in range(8):
+            for (w, h) in ((8, 8), (8, 8), (16, 16), (32, 16), (8, 4), (4, 4)):
+                if method == J.UMH and w == 4 and h == 4:
+                    continue
+                n = 2
+                px = rng.integers(0, (W - w) // 4 + 1, n) * 4
+                py = rng.integers(0, (H - h) // 4 + 1, n) * 4
+                qmvp = (int(rng.integers(-40, 40)), int(rng.integers(-40, 40)))
+                k = int(rng.integers(0, 5))
+                mvc = rng.integers(-60, 60, (k, 2)) if k else None
+                out.append(J.make_jobs(W, H, px, py, w, h, method=method, subme=subme,
+                                       merange=8 if method == J.FULL else 16, qp=int(rng.choice([12, 22, 32])),
+                                       qmvp=qmvp, mvc=mvc))
+    return np.concatenate(out)
+
+
+def plane_crc(planes) -> np.ndarray:
+    import zlib
+    return np.array([zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in planes], dtype=np.uint32)
+
+
+def run_lowres_suite(impl, bits: int) -> dict:
+    """impl: Reference or Oracle of tests/oracle_ffi.py"""
+    fr = lowres_source_frames(bits)
+    g, enc4 = impl.lowres_init(fr[0])
+    _, ref4 = impl.lowres_init(fr[1])
+    out = {"crc_enc": plane_crc(enc4), "crc_ref": plane_crc(ref4)}
+    jobs = lowres_jobs(g, bits)
+    r = impl.search(enc4[0], [ref4], jobs, lowres=True)
+    out["jobs"] = r[0] if isinstance(r, tuple) else r
+    for k, (method, subme, merange, qp) in enumerate(LOOKAHEAD_CONFIGS):
+        r = impl.lookahead_me(enc4, ref4, g.cu_w, g.cu_h, merange, method, subme, qp)
+        out["field%d" % k] = r[0] if isinstance(r, tuple) else r
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Suite runners.  `impl` is any object with the primitive-level interface of
 # tests/oracle_ffi.py (Reference / Oracle) or the product adapter of the gpu tests.

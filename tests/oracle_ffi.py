@@ -63,6 +63,11 @@ class Oracle:
         L.meo_buf_cost.restype = C.c_int
         L.meo_buf_cost.argtypes = [C.POINTER(MeoPlane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
         L.meo_lowres_core_u8.argtypes = [C.c_void_p] * 5 + [C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int]
+        L.meo_lowres_init.restype = None
+        L.meo_lowres_init.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.POINTER(C.c_void_p), C.c_ssize_t,
+                                      C.c_int, C.c_int, C.c_int, C.c_int]
+        L.meo_lookahead_me.restype = C.c_int64
+        L.meo_lookahead_me.argtypes = [C.POINTER(MeoPlane), C.POINTER(MeoPlane)] + [C.c_int] * 6 + [C.c_void_p]
 
     @staticmethod
     def _suf(a):
@@ -98,13 +103,37 @@ class Oracle:
                 p.lowres[i] = plane_origin(lowres[i], margin)
         return p
 
-    def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN):
-        """returns (results, evals)"""
+    def lowres_init(self, src_padded: np.ndarray, margin: int = MARGIN):
+        """(geometry, [F, H, V, C] padded planes) of a border-replicated source plane"""
+        from x265_amd.lowres import lowres_geometry
+        sw, sh = src_padded.shape[1] - 2 * margin, src_padded.shape[0] - 2 * margin
+        g = lowres_geometry(sw, sh, margin, margin)
+        planes = [np.zeros(g.padded_shape, dtype=src_padded.dtype) for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[plane_origin(p, margin) for p in planes])
+        self.lib.meo_lowres_init(plane_origin(src_padded, margin), src_padded.shape[1], src_padded.itemsize, ptrs,
+                                 g.stride, g.width, g.lines, margin, margin)
+        return g, planes
+
+    def lookahead_me(self, enc4, ref4, cu_w, cu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN):
+        """results[cu_h * cu_w] (raster) and evaluation count of one lookahead motion search"""
+        enc = self.make_plane(enc4[0], bit_depth, margin, lowres=enc4)
+        ref = self.make_plane(ref4[0], bit_depth, margin, lowres=ref4)
+        out = np.zeros(cu_w * cu_h, dtype=RESULT_DTYPE)
+        ev = self.lib.meo_lookahead_me(C.byref(enc), C.byref(ref), cu_w, cu_h, merange, method, subme, qp, out.ctypes.data)
+        return out, ev
+
+    def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN, lowres=False):
+        """returns (results, evals).  lowres: every entry of ref_padded_list is a list of the four
+        half-resolution planes (the search then takes the isLowres branches)"""
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
-        if not isinstance(ref_padded_list, (list, tuple)):
+        if not isinstance(ref_padded_list, (list, tuple)) or (lowres and isinstance(ref_padded_list[0], np.ndarray)):
             ref_padded_list = [ref_padded_list]
         enc = self.make_plane(enc_padded, bit_depth, margin)
-        refs = (MeoPlane * len(ref_padded_list))(*[self.make_plane(r, bit_depth, margin) for r in ref_padded_list])
+        if lowres:
+            refs = (MeoPlane * len(ref_padded_list))(*[self.make_plane(r[0], bit_depth, margin, lowres=r)
+                                                       for r in ref_padded_list])
+        else:
+            refs = (MeoPlane * len(ref_padded_list))(*[self.make_plane(r, bit_depth, margin) for r in ref_padded_list])
         out = np.zeros(len(jobs), dtype=RESULT_DTYPE)
         evals = self.lib.meo_search_batch(C.byref(enc), refs, jobs.ctypes.data, len(jobs), out.ctypes.data, threads)
         return out, evals
@@ -139,6 +168,9 @@ class Reference:
         L.ref_me_buf.restype = C.c_int
         L.ref_me_buf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
         L.ref_lowres_core.argtypes = [C.c_void_p] * 5 + [C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int]
+        L.ref_lookahead_me.restype = None
+        L.ref_lookahead_me.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_ssize_t] + \
+                                      [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
         self.me = L.ref_me_new()
 
     def set_bit_depth(self, depth):
@@ -174,10 +206,38 @@ class Reference:
         else:
             self.lib.ref_ipfilter_sp_v(_ptr(src, src_off), ss, _ptr(dst, dst_off), ds, w, h, frac)
 
-    def search(self, enc_padded, ref_padded_list, jobs, margin: int = MARGIN):
+    def lowres_init(self, src_padded: np.ndarray, margin: int = MARGIN):
+        """frame_init_lowres_core of the compiled reference + replicated borders (numpy): what
+        Lowres::init produces for a source whose margins hold replicated borders"""
+        from x265_amd.lowres import lowres_geometry
+        sw, sh = src_padded.shape[1] - 2 * margin, src_padded.shape[0] - 2 * margin
+        g = lowres_geometry(sw, sh, margin, margin)
+        inner = [np.zeros((g.lines, g.width), dtype=src_padded.dtype) for _ in range(4)]
+        self.lib.ref_lowres_core(plane_origin(src_padded, margin), *[p.ctypes.data for p in inner],
+                                 src_padded.shape[1], g.width, g.width, g.lines)
+        planes = []
+        for p in inner:
+            q = np.zeros(g.padded_shape, dtype=src_padded.dtype)
+            q[:, :g.width + 2 * margin] = np.pad(p, margin, mode="edge")
+            planes.append(q)
+        return g, planes
+
+    def lookahead_me(self, enc4, ref4, cu_w, cu_h, merange, method, subme, qp, margin: int = MARGIN):
+        ep = (C.c_void_p * 4)(*[plane_origin(p, margin) for p in enc4])
+        rp = (C.c_void_p * 4)(*[plane_origin(p, margin) for p in ref4])
+        mv = np.zeros((cu_w * cu_h, 2), dtype=np.int16)
+        cost = np.zeros(cu_w * cu_h, dtype=np.int32)
+        self.lib.ref_lookahead_me(self.me, ep, rp, enc4[0].shape[1], cu_w, cu_h, merange, method, subme, qp,
+                                  mv.ctypes.data, cost.ctypes.data)
+        out = np.zeros(cu_w * cu_h, dtype=RESULT_DTYPE)
+        out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
+        return out
+
+    def search(self, enc_padded, ref_padded_list, jobs, margin: int = MARGIN, lowres=False):
         """Runs every job through MotionEstimate::motionEstimate; returns RESULT_DTYPE array.
-        Jobs with icost != 0 have no reference counterpart and are rejected."""
-        if not isinstance(ref_padded_list, (list, tuple)):
+        Jobs with icost != 0 have no reference counterpart and are rejected.
+        lowres: every entry of ref_padded_list is a list of the four half-resolution planes."""
+        if not isinstance(ref_padded_list, (list, tuple)) or (lowres and isinstance(ref_padded_list[0], np.ndarray)):
             ref_padded_list = [ref_padded_list]
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         out = np.zeros(len(jobs), dtype=RESULT_DTYPE)
@@ -186,13 +246,17 @@ class Reference:
         for i, j in enumerate(jobs):
             assert j["icost"] == 0
             ref = ref_padded_list[int(j["ref_idx"])]
+            lr = None
+            if lowres:
+                lr = (C.c_void_p * 4)(*[plane_origin(p, margin) for p in ref])
+                ref = ref[0]
             assert ref.shape[1] == es, "the reference applies one blockOffset to both planes"
             mvmin = np.array([j["mvmin_x"], j["mvmin_y"]], dtype=np.int16)
             mvmax = np.array([j["mvmax_x"], j["mvmax_y"]], dtype=np.int16)
             qmvp = np.array([j["qmvp_x"], j["qmvp_y"]], dtype=np.int16)
             mvc = np.ascontiguousarray(j["mvc"], dtype=np.int16)
             omv = np.zeros(2, dtype=np.int16)
-            cost = self.lib.ref_me_search(self.me, enc0, es, plane_origin(ref, margin), ref.shape[1], None,
+            cost = self.lib.ref_me_search(self.me, enc0, es, plane_origin(ref, margin), ref.shape[1], lr,
                                           int(j["pu_y"]) * es + int(j["pu_x"]), int(j["w"]), int(j["h"]),
                                           mvmin.ctypes.data, mvmax.ctypes.data, qmvp.ctypes.data,
                                           int(j["numc"]), mvc.ctypes.data, int(j["merange"]),

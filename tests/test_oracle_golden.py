@@ -75,3 +75,13 @@ def test_full_search_field_matches_reference_vectors(oracle):
     fr = G.field_frames()
     got, _ = oracle.search(fr[0], [fr[1]], jobs, threads=4)
     assert np.array_equal(got, gold["res"])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_lookahead_path_matches_reference_vectors(oracle, bits):
+    """half-resolution planes (CRC), isLowres searches and the lookahead's neighbour-predicted MV fields"""
+    gold = _load("lowres_u%d.npz" % bits)
+    got = G.run_lowres_suite(oracle, bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.nonzero(gold[k] != got[k])[0][:5])
