@@ -79,6 +79,30 @@ int x265amd_plane_wrap_device(x265amd_ctx *ctx, void *dev_base, int width, int h
 void *x265amd_plane_device_ptr(x265amd_ctx *ctx, int plane_id);
 int x265amd_plane_release(x265amd_ctx *ctx, int plane_id);
 
+/* copy plane `which` of a registered plane (0; 0..3 = F, H, V, C for a half-resolution set) back
+ * to the host: `bytes` from the start of its padded allocation (tests, debugging) */
+int x265amd_plane_download(x265amd_ctx *ctx, int plane_id, int which, void *host, size_t bytes);
+
+/* ---- lookahead: half-resolution planes --------------------------------------------------
+ * Lowres::create + the picture part of Lowres::init (common/lowres.cpp:30-58, 132-185): the four
+ * half-resolution planes of a registered full-resolution plane -- F (2x2 means) and the half-pel
+ * shifted H, V, C (frame_init_lowres_core, common/pixel.cpp:614-637) -- computed and
+ * border-extended on the device, in one allocation, with the source's margins and
+ * stride = (width/2 + 2*margin_x) rounded up to 32; width and lines are rounded up to whole 8x8
+ * CUs.  The source's margins must hold replicated borders and be >= 16 pixels.  The returned id
+ * is a plane id: as a job's reference it stands for ReferencePlanes with isLowres set
+ * (common/reference.h:36-53), so sub-pel candidates take the half-pel-plane averaging branch of
+ * subpelCompare (encoder/motion.cpp:1112-1137); as an encoder plane it is its F plane
+ * (Lowres::lowresPlane[0], encoder/slicetype.cpp:306).  Release with x265amd_plane_release. */
+int x265amd_lowres_create(x265amd_ctx *ctx, int src_plane, int *lowres_plane);
+/* Lowres::init for a new picture into an existing set of the same geometry (no allocation);
+ * asynchronous on the context's stream */
+int x265amd_lowres_update(x265amd_ctx *ctx, int lowres_plane, int src_plane);
+/* Lowres::width / lines / lumaStride and Lookahead::widthInCU / heightInCU
+ * (common/lowres.cpp:35-46, encoder/slicetype.cpp:74-75); any pointer may be NULL */
+int x265amd_lowres_geometry(x265amd_ctx *ctx, int lowres_plane, int *width, int *lines, intptr_t *stride,
+                            int *cu_w, int *cu_h);
+
 /* ---- batched block costs -------------------------------------------------------------
  * n independent evaluations of EncoderPrimitives::sad / satd / sa8d_inter
  * [PartitionFromSizes(w,h)] (common/primitives.h:242-249, common/pixel.cpp:645-826):
@@ -143,6 +167,20 @@ int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, 
                         x265amd_me_result *out);
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
 int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
+
+/* ---- lookahead: whole-frame motion search ------------------------------------------------
+ * The motion-search part of Lookahead::estimateFrameCost / estimateCUCost for one reference list
+ * (encoder/slicetype.cpp:306-316, 346-369, 381-407) for n_pairs (encoder frame, reference frame)
+ * pairs of half-resolution sets of one geometry: every 8x8 CU, in an order equivalent to the
+ * reference's reverse raster scan, searched with mvp = median of / candidates = the MVs of its
+ * right, lower, lower-left and lower-right neighbours and bounds that keep the block within 8
+ * pixels of the picture.  The reference's lookahead uses method HEX, subme 1, merange 16,
+ * qp X265_LOOKAHEAD_QP (encoder/slicetype.cpp:70-73).
+ * out[pair * cu_w*cu_h + cux + cuy*cu_w] = (lowresMvs, lowresMvCosts) of that CU.
+ * out == NULL: asynchronous, results stay in device memory (x265amd_lookahead_results_device). */
+int x265amd_lookahead_me(x265amd_ctx *ctx, int n_pairs, const int *enc_lowres, const int *ref_lowres,
+                         int merange, int method, int subme, int qp, x265amd_me_result *out);
+const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last
  * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */

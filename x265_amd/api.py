@@ -70,6 +70,13 @@ def load_library() -> C.CDLL:
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
     L.x265amd_plane_device_ptr.restype = vp
     L.x265amd_plane_release.argtypes = [vp, ci]
+    L.x265amd_plane_download.argtypes = [vp, ci, ci, vp, C.c_size_t]
+    L.x265amd_lowres_create.argtypes = [vp, ci, cip]
+    L.x265amd_lowres_update.argtypes = [vp, ci, ci]
+    L.x265amd_lowres_geometry.argtypes = [vp, ci, cip, cip, C.POINTER(C.c_ssize_t), cip, cip]
+    L.x265amd_lookahead_me.argtypes = [vp, ci, cip, cip, ci, ci, ci, ci, vp]
+    L.x265amd_lookahead_results_device.argtypes = [vp]
+    L.x265amd_lookahead_results_device.restype = vp
     L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
@@ -150,6 +157,45 @@ class Engine:
 
     def release_plane(self, pid: int):
         self._chk(self.lib.x265amd_plane_release(self.h, pid))
+
+    # -- lookahead: half-resolution planes and whole-frame search ------------------------------
+    def lowres_create(self, src_plane: int) -> int:
+        """half-resolution F/H/V/C plane set of a registered full-resolution plane; returns its plane id"""
+        pid = C.c_int(-1)
+        self._chk(self.lib.x265amd_lowres_create(self.h, src_plane, C.byref(pid)))
+        return pid.value
+
+    def lowres_update(self, lowres_plane: int, src_plane: int):
+        self._chk(self.lib.x265amd_lowres_update(self.h, lowres_plane, src_plane))
+
+    def lowres_geometry(self, lowres_plane: int):
+        """(width, lines, stride, cu_w, cu_h)"""
+        w, l, cw, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        st = C.c_ssize_t()
+        self._chk(self.lib.x265amd_lowres_geometry(self.h, lowres_plane, C.byref(w), C.byref(l), C.byref(st),
+                                                   C.byref(cw), C.byref(ch)))
+        return w.value, l.value, st.value, cw.value, ch.value
+
+    def download_plane(self, plane: int, shape, dtype, which: int = 0) -> np.ndarray:
+        """the padded allocation of a plane (or plane `which` of a half-resolution set) as an array"""
+        out = np.zeros(shape, dtype=dtype)
+        self._chk(self.lib.x265amd_plane_download(self.h, plane, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def lookahead_me(self, enc_lowres, ref_lowres, merange: int = 16, method: int = 1, subme: int = 1, qp: int = 12,
+                     fetch: bool = True):
+        """whole-frame lookahead searches of (enc, ref) half-resolution pairs; returns
+        results[n_pairs, cu_h * cu_w] (raster order), or None with fetch=False (asynchronous)"""
+        enc_lowres, ref_lowres = list(enc_lowres), list(ref_lowres)
+        n = len(enc_lowres)
+        assert n == len(ref_lowres) and n > 0
+        _, _, _, cw, ch = self.lowres_geometry(enc_lowres[0])
+        e = (C.c_int * n)(*enc_lowres)
+        r = (C.c_int * n)(*ref_lowres)
+        out = np.zeros((n, cw * ch), dtype=RESULT_DTYPE) if fetch else None
+        self._chk(self.lib.x265amd_lookahead_me(self.h, n, e, r, merange, method, subme, qp,
+                                                out.ctypes.data if fetch else None))
+        return out
 
     # -- costs --------------------------------------------------------------------------------
     def cost_batch(self, kind: int, w: int, h: int, pairs: np.ndarray) -> np.ndarray:

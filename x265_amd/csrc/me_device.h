@@ -42,6 +42,8 @@ struct PlaneDesc
     int32_t bpp;          // bytes per pixel
     int32_t depth;        // bit depth seen by the interpolation filters
     int32_t margin_x, margin_y;
+    int64_t lr_step;      // 0, or: this is the F plane of a half-resolution set whose H, V, C planes follow
+                          // 1, 2, 3 x lr_step elements behind it (ReferencePlanes::lowresPlane, common/reference.h:36-53)
 };
 
 struct P4 { int v[4]; };
@@ -193,7 +195,12 @@ __device__ __forceinline__ void group_xy(int g, int w, int h, int &x, int &y)
 
 // ------------------------------------------------------------------ per-job state in LDS
 
-enum { PRED_INT = 0, PRED_H = 1, PRED_V = 2, PRED_HV = 3 };
+enum { PRED_INT = 0, PRED_H = 1, PRED_V = 2, PRED_HV = 3, PRED_LR = 4 };
+
+// Phase word of a candidate (JobState::frc).  Full-resolution reference: xf | yf << 2.  Half-resolution
+// set (subpelCompare's isLowres branch, encoder/motion.cpp:1112-1137): LR_FLAG | plane A | plane B << 2 |
+// average << 4 | (B's block origin relative to A's: dx << 5 | dy << 6).
+enum { LR_FLAG = 0x80 };
 
 constexpr int CS_LEN = 160;         // entries of the MV-cost slice kept in LDS: MVDs within +-20 pixels of the predictor
 constexpr int CS_LO = -CS_LEN / 2;  // MVD of its first entry (a multiple of 8: 16-byte aligned copies)
@@ -223,7 +230,7 @@ struct JobState
     int32_t  stride, depth;
     int32_t  w, h, G, T;            // PU size, 4-pixel groups, passes over the job's lanes
     int32_t  mvpx, mvpy;            // q-pel predictor the MV costs are relative to
-    int32_t  sliced, pad0;          // the LDS cost slice is staged
+    int32_t  sliced, lrstep;        // the LDS cost slice is staged; PlaneDesc::lr_step of the reference
     int32_t  wx0, wy0, ww, wh;      // reference window as last staged: origin relative to the PU origin, size (pixels)
     int32_t  wpitch, pad;           // its pitch in bytes
     int32_t  pts[8];                // candidates of the next eval call: offset of the block origin (window bytes / plane pixels)
@@ -391,6 +398,19 @@ struct Dev
                     r[0] = (uint32_t)v;
                     r[1] = (uint32_t)(v >> 32);
                 }
+            }
+        }
+        // 4 pixels of another plane of a half-resolution set: `add` elements behind the clamped position
+        __device__ __forceinline__ void rd4_plane(int off, int add, uint32_t *r) const
+        {
+            const PIX *q = refbase + clamp_off(off, 4) + add;
+            if (DW == 1)
+                r[0] = ld_u32(q);
+            else
+            {
+                uint64_t v = ld_u64(q);
+                r[0] = (uint32_t)v;
+                r[1] = (uint32_t)(v >> 32);
             }
         }
         // 12 pixels as packed dwords: u8 -> r[0..2]; u16 -> r[0..5]
@@ -750,7 +770,7 @@ struct Dev
     // element `ioff`.  `mode` is uniform: the switch is a scalar branch.
     template <bool LW>
     static __device__ __forceinline__ P4 pred4(const View &v, const Src &src, int mode, int off, int pitch, int ioff, int w,
-                                               int depth_rt, int xf, int yf)
+                                               int depth_rt, int xf, int yf, int lr)
     {
         constexpr int step = LW ? PB : 1;
         if (mode == PRED_INT)
@@ -758,6 +778,26 @@ struct Dev
             uint32_t d[2];
             src.template rd4_packed<LW>(off, d);
             return unpack4(d);
+        }
+        if (mode == PRED_LR)       // half-resolution reference: a half-pel plane, or the rounded mean of two
+        {                          // (encoder/motion.cpp:1114-1136); always read from the planes
+            const int step_lr = v.s->lrstep;
+            uint32_t a[2], b[2];
+            src.rd4_plane(off, (lr & 3) * step_lr, a);
+            if (!(lr & 0x10))
+                return unpack4(a);
+            src.rd4_plane(off + ((lr >> 5) & 1) + ((lr >> 6) & 1) * pitch, ((lr >> 2) & 3) * step_lr, b);
+            if (DW == 1)
+            {
+                a[0] = __builtin_amdgcn_lerp(a[0], b[0], 0x01010101u);     // per byte (a + b + 1) >> 1
+                return unpack4(a);
+            }
+            const P4 pa = unpack4(a), pb = unpack4(b);
+            P4 r;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                r.v[i] = (pa.v[i] + pb.v[i] + 1) >> 1;
+            return r;
         }
         const int depth = DW == 1 ? 8 : depth_rt;     // 8-bit planes: every shift and bound is a constant
         const int hr = 14 - depth;
@@ -848,11 +888,13 @@ struct Dev
     // the instruction footprint small.
     struct HvCache { int off, xf; bool valid; };    // which horizontal intermediate LDS holds (uniform)
 
-    static __device__ __forceinline__ int cost_body(View &v, const Src &src, bool lw, int off, int pitch, int xf, int yf,
+    static __device__ __forceinline__ int cost_body(View &v, const Src &src, bool lw, int off, int pitch, int frac,
                                                     int kind, int par, HvCache &hc)
     {
         const int w = uni(v.s->w), h = uni(v.s->h), depth = v.s->depth;
-        const int mode = (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
+        const bool lr = (frac & LR_FLAG) != 0;
+        const int xf = lr ? 0 : frac & 3, yf = lr ? 0 : (frac >> 2) & 3;
+        const int mode = lr ? PRED_LR : (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
         const bool m8 = ((w | h) & 7) == 0;
         const bool m16 = ((w | h) & 15) == 0;
         int hv_row = 0;             // first intermediate row of this candidate
@@ -884,8 +926,8 @@ struct Dev
                     fd[1] = v.l->fenc[DW * g + 1];
                 const P4 f = unpack4(fd);
                 const int lo = off + gy * pitch + gx * (lw ? PB : 1);
-                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf)
-                                : pred4<false>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf);
+                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf, frac)
+                                : pred4<false>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf, frac);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     d[i] = f.v[i] - r.v[i];
@@ -998,7 +1040,7 @@ struct Dev
         for (int k = 0; k < n; k++)
         {
             const int off = v.s->pts[k], frac = uni(v.s->frc[k]);
-            const int c = cost_body(v, src, lw, off, pitch, frac & 3, frac >> 2, kind, par, hc);
+            const int c = cost_body(v, src, lw, off, pitch, frac, kind, par, hc);
             res += (v.lane == k) ? c : 0;
             par ^= 1;
         }
@@ -1067,6 +1109,7 @@ struct Wave
     typename D::SP s;
     int w, h, stride, mvpx, mvpy, ikind, jflags;
     bool sliced;                    // the LDS cost slice is staged
+    bool lowres;                    // the reference is a half-resolution set (ReferencePlanes::isLowres)
     const uint16_t *cost;
     int wx0, wy0, ww, wh, wpitch;   // reference window: origin relative to the PU origin, size (pixels), pitch (bytes)
     bool wvalid;
@@ -1107,6 +1150,8 @@ struct Wave
         s->w = w; s->h = h; s->G = G; s->T = (G + NT - 1) / NT;
         s->mvpx = 0; s->mvpy = 0;
         s->sliced = 0;
+        lowres = ref.lr_step != 0;
+        s->lrstep = (int32_t)ref.lr_step;
         const PIX *e = (const PIX*)enc.origin + (int64_t)enc_y * enc.stride + enc_x;
         D::post(base, D::OP_FILL, (int)(uint32_t)(uint64_t)e, (int)((uint64_t)e >> 32), enc.stride);
         D::fill_pu(base, (uint64_t)e, enc.stride);
@@ -1194,8 +1239,9 @@ struct Wave
             miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
         }
         const bool multi = kind == X265AMD_SAD && !frac;
-        // a lone full-pel SAD (predictor checks, clipped pattern points) does not move the window
-        const int where = place(minx, miny, maxx, maxy, !(N == 1 && multi));
+        // a lone full-pel SAD (predictor checks, clipped pattern points) does not move the window;
+        // phases of a half-resolution set select other planes than the one the window caches
+        const int where = (frac && lowres) ? 0 : place(minx, miny, maxx, maxy, !(N == 1 && multi));
         constexpr int NP = N == 1 ? 1 : N <= 4 ? 4 : 8;     // candidates the SAD pass measures
 #pragma unroll
         for (int k = 0; k < NP; k++)
@@ -1260,11 +1306,22 @@ struct Wave
         return c;
     }
 
-    // subpelCompare for a full-resolution reference (motion.cpp:1140-1165) at q-pel (qx,qy);
-    // with_mv: plus mvcost(MV(qx,qy))
+    // phase word of q-pel position (qx,qy) (see LR_FLAG)
+    __device__ __forceinline__ int phase(int qx, int qy) const
+    {
+        if (!lowres)
+            return (qx & 3) | ((qy & 3) << 2);
+        // motion.cpp:1117-1122: plane A from the half-pel bits; with an odd component the mean of A and
+        // the plane B of the position rounded away (qmvB = qmv + (qx & 1, qy & 1) * 2)
+        const int bx = (int16_t)(qx + (qx & 1) * 2), by = (int16_t)(qy + (qy & 1) * 2);
+        const int ha = (qy & 2) | ((qx & 2) >> 1), hb = (by & 2) | ((bx & 2) >> 1);
+        return LR_FLAG | ha | (hb << 2) | (((qx | qy) & 1) << 4) | (((bx >> 2) - (qx >> 2)) << 5) | (((by >> 2) - (qy >> 2)) << 6);
+    }
+
+    // subpelCompare (motion.cpp:1110-1166) at q-pel (qx,qy); with_mv: plus mvcost(MV(qx,qy))
     __device__ __forceinline__ int subpel_cost(int qx, int qy, int kind, bool with_mv)
     {
-        const int cx = qx >> 2, cy = qy >> 2, fr = (qx & 3) | ((qy & 3) << 2);
+        const int cx = qx >> 2, cy = qy >> 2, fr = phase(qx, qy);
         int c;
         eval_n<1>(1, &cx, &cy, &qx, &qy, kind, &fr, with_mv ? 0 : CF_NOMV, &c);
         return c;
@@ -1278,7 +1335,7 @@ struct Wave
         for (int k = 0; k < 8; k++)
         {
             cx[k] = qx[k] >> 2; cy[k] = qy[k] >> 2;
-            fr[k] = (qx[k] & 3) | ((qy[k] & 3) << 2);
+            fr[k] = phase(qx[k], qy[k]);
         }
         eval_n<8>(n, cx, cy, qx, qy, kind, fr, 0, out);
     }

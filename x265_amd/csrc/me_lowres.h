@@ -1,0 +1,230 @@
+// The lookahead's half-resolution path (gfx950): producing the four half-pel planes of a picture
+// and searching a whole half-resolution frame with the reference's neighbour-predicted MV chain.
+//
+// Reference semantics being reproduced (paths relative to the reference's source/):
+//   frame_init_lowres_core          common/pixel.cpp:614-637
+//   Lowres::create / Lowres::init   common/lowres.cpp:30-58, 109-186
+//   border extension                Lib/TLibCommon/TComPicYuv.cpp:259-286
+//   Lookahead::estimateFrameCost / estimateCUCost, motion-search part
+//                                   encoder/slicetype.cpp:48-63, 306-316, 346-369, 381-407
+#pragma once
+
+#include "me_kernels.h"
+
+namespace xa {
+
+// ------------------------------------------------------------------------------------------
+// Half-resolution planes.  One thread produces 4 adjacent pixels of all four planes (F, H, V, C)
+// at one position of the PADDED output domain: positions in the margins take the value of the
+// nearest picture pixel, which is what extending the borders afterwards yields.  The source is a
+// border-replicated plane; its reads reach at most 2 pixels beyond twice the rounded-up
+// half-resolution size (<= 16 pixels into its margins).
+template <typename PIX>
+__global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo, int64_t shi, int sstride,
+                                                     PIX *dst, int dstride, int rows, int width, int lines,
+                                                     int mx, int my, int64_t lr_step)
+{
+    const int per_row = dstride >> 2;
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (t >= per_row * rows)
+        return;
+    const int y = t / per_row, x0 = (t - y * per_row) * 4;
+    int py = y - my;
+    py = py < 0 ? 0 : py > lines - 1 ? lines - 1 : py;
+    uint32_t o[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        int px = x0 + i - mx;
+        px = px < 0 ? 0 : px > width - 1 ? width - 1 : px;
+        uint32_t a[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+                int64_t off = (int64_t)(2 * py + r) * sstride + 2 * px + c;
+                off = off < slo ? slo : off > shi - 1 ? shi - 1 : off;      // (never outside a plane with 16-pixel margins)
+                a[r][c] = src[off];
+            }
+        // "slower than naive bilinear, but matches asm": two rounded means, then their rounded mean
+        auto avg4 = [](uint32_t p, uint32_t q, uint32_t r, uint32_t s) { return (((p + q + 1) >> 1) + ((r + s + 1) >> 1) + 1) >> 1; };
+        o[0][i] = avg4(a[0][0], a[1][0], a[0][1], a[1][1]);
+        o[1][i] = avg4(a[0][1], a[1][1], a[0][2], a[1][2]);
+        o[2][i] = avg4(a[1][0], a[2][0], a[1][1], a[2][1]);
+        o[3][i] = avg4(a[1][1], a[2][1], a[1][2], a[2][2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        PIX *q = dst + k * lr_step + (int64_t)y * dstride + x0;
+        if (sizeof(PIX) == 1)
+            *(uint32_t*)q = o[k][0] | (o[k][1] << 8) | (o[k][2] << 16) | (o[k][3] << 24);
+        else
+            *(uint2*)q = make_uint2(o[k][0] | (o[k][1] << 16), o[k][2] | (o[k][3] << 16));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole-frame lookahead search.  The reference walks the 8x8 CUs of the half-resolution frame in
+// reverse raster order on one thread; a CU's predictor and candidates are the MVs of its right,
+// lower, lower-left and lower-right neighbours.  Here one wavefront owns one CU ROW and walks it
+// right to left; it may search CU (x, y) once the row below has finished CU x - 1, so the rows
+// form a wavefront two CUs apart and the result is the reference's, bit for bit.
+//
+// Hand-over between rows: the owner writes the CU's result, then release-stores its row's count of
+// finished CUs (device scope); the row above acquire-loads that count.  Row y waits only on row
+// y + 1, i.e. workgroup b only on workgroup b - 1 of the same pair, which was dispatched earlier:
+// the chain always makes progress.  A bounded spin guards against a lost predecessor.
+struct LookPair { int32_t enc_plane, ref_plane; };
+
+constexpr int LOOK_SPIN_LIMIT = 1 << 24;
+
+struct LookLeaf
+{
+    // Wait until *count >= need (or the spin limit); 0 on success.  Out of line: the kernel body keeps
+    // only uniform control flow.
+    static __device__ __noinline__ int wait_count(const int *count, int need_)
+    {
+        const int need = uni(need_);
+        for (int spin = 0; spin < LOOK_SPIN_LIMIT; spin++)
+        {
+            const int c = uni(__hip_atomic_load(count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+            if (c >= need)
+                return 0;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        return 1;
+    }
+    // MV word (mvy << 16 | mvx & 0xffff) of a finished CU of another row
+    static __device__ __noinline__ int load_mv(const x265amd_me_result *r)
+    {
+        return uni(__hip_atomic_load((const int*)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    // one lane publishes a CU's result and then the row's new count
+    static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost, int *count, int done)
+    {
+        if (threadIdx.x == 0)
+        {
+            x265amd_me_result r;
+            r.mvx = (int16_t)mvx;
+            r.mvy = (int16_t)mvy;
+            r.cost = cost;
+            *out = r;
+            __hip_atomic_store(count, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    static __device__ __noinline__ void finish(unsigned long long *evals, unsigned n_evals, int *error, int failed)
+    {
+        if (threadIdx.x == 0)
+        {
+            atomicAdd(evals, (unsigned long long)n_evals);
+            if (failed)
+                atomicOr(error, 1);
+        }
+    }
+};
+
+// median() of encoder/slicetype.cpp:48-57 with its 16-bit intermediates
+__device__ __forceinline__ int look_median(int a, int b, int c)
+{
+    int t = XA_S16(a - b < 0 ? a - b : 0);
+    a = XA_S16(a - t);
+    b = XA_S16(b + t);
+    b = XA_S16(b - (b - c < 0 ? b - c : 0));
+    b = XA_S16(b + (a - b < 0 ? a - b : 0));
+    return b;
+}
+
+template <class L>
+__global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
+                                                  int cu_w, int cu_h, int merange, int method, int subme, int qp, int flags,
+                                                  x265amd_me_result *out, int *progress, int *error,
+                                                  unsigned long long *evals)
+{
+    static_assert(L::NW == 1, "one wavefront per CU row");
+    __shared__ __align__(16) L lds;
+    const int pair = (int)blockIdx.x / cu_h;
+    const int cuy = cu_h - 1 - ((int)blockIdx.x - pair * cu_h);         // workgroup 0 of a pair: the bottom row
+    const PlaneDesc &enc = planes[pairs[pair].enc_plane];
+    const PlaneDesc &ref = planes[pairs[pair].ref_plane];
+    x265amd_me_result *res = out + (size_t)pair * cu_w * cu_h;
+    int *count = progress + (size_t)pair * cu_h;
+    const bool have_b = cuy < cu_h - 1;
+    unsigned n_evals = 0;
+    int failed = 0;
+    int right = 0;                                                       // MV word of the CU searched last (right neighbour)
+
+    for (int cux = cu_w - 1; cux >= 0; cux--)
+    {
+        const bool have_r = cux < cu_w - 1;
+        if (have_b)
+        {
+            int need = cu_w - cux + 1;
+            need = need > cu_w ? cu_w : need;
+            failed |= uni(LookLeaf::wait_count(count + cuy + 1, need));     // (results of calls arrive in vector registers)
+        }
+        // slicetype.cpp:385-405: candidates right, below, below-left, below-right (those that exist),
+        // appended in that order; unused entries 0 and 2 are zero vectors
+        int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, numc = 0;
+        auto push = [&](bool have, int word)
+        {
+            if (have)
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (numc == k)
+                    {
+                        cx[k] = XA_S16(word & 0xffff);
+                        cy[k] = XA_S16(word >> 16);
+                    }
+                numc++;
+            }
+        };
+        const x265amd_me_result *below = res + (size_t)(cuy + 1) * cu_w + cux;
+        push(have_r, right);
+        push(have_b, have_b ? uni(LookLeaf::load_mv(below)) : 0);
+        push(have_b && cux > 0, (have_b && cux > 0) ? uni(LookLeaf::load_mv(below - 1)) : 0);
+        push(have_b && have_r, (have_b && have_r) ? uni(LookLeaf::load_mv(below + 1)) : 0);
+
+        JobRegs j;
+        j.pu_x = 8 * cux;
+        j.pu_y = 8 * cuy;
+        j.w = j.h = 8;
+        // search bounds that do not cross the extended frame (slicetype.cpp:366-369)
+        j.mvmin_x = XA_S16(-cux * 8 - 8);
+        j.mvmin_y = XA_S16(-cuy * 8 - 8);
+        j.mvmax_x = XA_S16((cu_w - cux - 1) * 8 + 8);
+        j.mvmax_y = XA_S16((cu_h - cuy - 1) * 8 + 8);
+        j.merange = merange; j.method = method; j.subme = subme; j.qp = qp;
+        j.numc = numc; j.ref_idx = 0; j.icost = X265AMD_SAD;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            j.mvc[k][0] = cx[k];
+            j.mvc[k][1] = cy[k];
+        }
+        if (numc <= 1)
+        {
+            j.qmvp_x = cx[0];
+            j.qmvp_y = cy[0];
+        }
+        else
+        {
+            j.qmvp_x = look_median(cx[0], cx[1], cx[2]);
+            j.qmvp_y = look_median(cy[0], cy[1], cy[2]);
+        }
+
+        Wave<L> W;
+        W.bind(lds, enc, ref, j.pu_x, j.pu_y, j.pu_x, j.pu_y, 8, 8, cost, flags);
+        Search<L> S(W, j);
+        int ox, oy;
+        const int c = S.run(nullptr, 0, ox, oy);
+        n_evals += W.evals;
+        right = (oy << 16) | (ox & 0xffff);
+        LookLeaf::publish(res + (size_t)cuy * cu_w + cux, ox, oy, c, count + cuy, cu_w - cux);
+    }
+    LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
+}
+
+} // namespace xa

@@ -2,6 +2,7 @@
 // Everything computes on the GPU; there is no host fallback.
 #include "me_kernels.h"
 #include "me_full.h"
+#include "me_lowres.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -62,7 +63,7 @@ struct x265amd_ctx
     uint16_t    *d_cost = nullptr;        // 52 x 65536
     unsigned long long *d_evals = nullptr;   // EVAL_SLOTS counters 16 words apart (+ 16 words of developer counters)
 
-    DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs;
+    DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
     bool   timing = false;
@@ -181,6 +182,7 @@ int add_plane(x265amd_ctx *c, void *dev_base, void *owned, int width, int height
     d.depth = depth;
     d.margin_x = margin_x;
     d.margin_y = margin_y;
+    d.lr_step = 0;
     c->used[id] = true;
     c->owned[id] = owned;
     c->base[id] = dev_base;
@@ -754,7 +756,8 @@ void x265amd_destroy(x265amd_ctx *c)
     for (int i = 0; i < MAX_PLANES; i++)
         if (c->used[i] && c->owned[i])
             hipFree(c->owned[i]);
-    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs };
+    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs,
+                       &c->look_pairs, &c->look_results, &c->look_progress };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -847,6 +850,206 @@ int x265amd_plane_release(x265amd_ctx *c, int id)
     memset(&c->h_planes[id], 0, sizeof(PlaneDesc));
     c->planes_dirty = true;
     return 0;
+}
+
+// ---- lookahead (half-resolution) path ------------------------------------------------------
+
+namespace {
+
+// geometry of Lowres::create (common/lowres.cpp:30-58) for a source plane
+struct LowresGeom { int width, lines, stride, cu_w, cu_h; int64_t elems; };
+
+LowresGeom lowres_geom(const PlaneDesc &s)
+{
+    LowresGeom g;
+    int width = s.width / 2, lines = s.height / 2;
+    g.stride = width + 2 * s.margin_x;
+    if (g.stride & 31)
+        g.stride += 32 - (g.stride & 31);
+    g.cu_w = (width + 7) >> 3;
+    g.cu_h = (lines + 7) >> 3;
+    g.width = g.cu_w * 8;
+    g.lines = g.cu_h * 8;
+    g.elems = (int64_t)g.stride * (g.lines + 2 * s.margin_y);
+    return g;
+}
+
+int lowres_fill(x265amd_ctx *c, int lowres_plane, int src_plane)
+{
+    const PlaneDesc &s = c->h_planes[src_plane], &d = c->h_planes[lowres_plane];
+    const int rows = d.height + 2 * d.margin_y;
+    const int threads = (d.stride / 4) * rows;
+    const dim3 grid((threads + 255) / 256), block(256);
+    if (s.bpp == 1)
+        hipLaunchKernelGGL(k_lowres_init<uint8_t>, grid, block, 0, c->stream, (const uint8_t*)s.origin, s.lo, s.hi, s.stride,
+                           (uint8_t*)c->base[lowres_plane], d.stride, rows, d.width, d.height, d.margin_x, d.margin_y, d.lr_step);
+    else
+        hipLaunchKernelGGL(k_lowres_init<uint16_t>, grid, block, 0, c->stream, (const uint16_t*)s.origin, s.lo, s.hi, s.stride,
+                           (uint16_t*)c->base[lowres_plane], d.stride, rows, d.width, d.height, d.margin_x, d.margin_y, d.lr_step);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int check_lowres_source(x265amd_ctx *c, int src_plane)
+{
+    if (src_plane < 0 || src_plane >= MAX_PLANES || !c->used[src_plane] || c->h_planes[src_plane].lr_step)
+        return fail(c, X265AMD_ERR_INVALID, "source is not a registered full-resolution plane");
+    const PlaneDesc &s = c->h_planes[src_plane];
+    if (s.width < 16 || s.height < 16)
+        return fail(c, X265AMD_ERR_INVALID, "source picture too small");
+    // the downscale reads up to 16 pixels beyond the picture; searches leave the half-resolution
+    // picture by up to 8 + 3 pixels plus one for the neighbouring half-pel plane
+    if (s.margin_x < 16 || s.margin_y < 16)
+        return fail(c, X265AMD_ERR_RANGE, "source margins below 16 pixels");
+    return 0;
+}
+
+} // namespace
+
+int x265amd_lowres_create(x265amd_ctx *c, int src_plane, int *lowres_plane)
+{
+    if (!c || !lowres_plane)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_lowres_source(c, src_plane)) return rc;
+    const PlaneDesc s = c->h_planes[src_plane];
+    const LowresGeom lg = lowres_geom(s);
+    void *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (size_t)(4 * lg.elems) * s.bpp + 64));
+    int id = -1;
+    int rc = add_plane(c, d, d, lg.width, lg.lines, s.margin_x, s.margin_y, lg.stride, s.bpp, s.depth, &id);
+    if (rc)
+    {
+        hipFree(d);
+        return rc;
+    }
+    c->h_planes[id].lr_step = lg.elems;
+    rc = lowres_fill(c, id, src_plane);
+    if (rc)
+        return rc;
+    *lowres_plane = id;
+    return 0;
+}
+
+int x265amd_lowres_update(x265amd_ctx *c, int lowres_plane, int src_plane)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_lowres_source(c, src_plane)) return rc;
+    if (lowres_plane < 0 || lowres_plane >= MAX_PLANES || !c->used[lowres_plane] || !c->h_planes[lowres_plane].lr_step)
+        return fail(c, X265AMD_ERR_INVALID, "not a half-resolution plane set");
+    const PlaneDesc &s = c->h_planes[src_plane], &d = c->h_planes[lowres_plane];
+    const LowresGeom lg = lowres_geom(s);
+    if (lg.width != d.width || lg.lines != d.height || lg.stride != d.stride || s.bpp != d.bpp ||
+        s.margin_x != d.margin_x || s.margin_y != d.margin_y)
+        return fail(c, X265AMD_ERR_INVALID, "source geometry does not match the half-resolution set");
+    return lowres_fill(c, lowres_plane, src_plane);
+}
+
+int x265amd_lowres_geometry(x265amd_ctx *c, int lowres_plane, int *width, int *lines, intptr_t *stride, int *cu_w, int *cu_h)
+{
+    if (!c || lowres_plane < 0 || lowres_plane >= MAX_PLANES || !c->used[lowres_plane] || !c->h_planes[lowres_plane].lr_step)
+        return X265AMD_ERR_INVALID;
+    const PlaneDesc &d = c->h_planes[lowres_plane];
+    if (width)  *width = d.width;
+    if (lines)  *lines = d.height;
+    if (stride) *stride = d.stride;
+    if (cu_w)   *cu_w = d.width / 8;
+    if (cu_h)   *cu_h = d.height / 8;
+    return 0;
+}
+
+int x265amd_plane_download(x265amd_ctx *c, int plane, int which, void *host, size_t bytes)
+{
+    if (!c || !host || plane < 0 || plane >= MAX_PLANES || !c->used[plane])
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const PlaneDesc &d = c->h_planes[plane];
+    if (which < 0 || which > (d.lr_step ? 3 : 0))
+        return fail(c, X265AMD_ERR_INVALID, "no such plane in the set");
+    const size_t have = (size_t)(d.hi - d.lo) * d.bpp;
+    if (bytes > have)
+        return fail(c, X265AMD_ERR_INVALID, "download larger than the plane");
+    HIPCHK(c, hipMemcpyAsync(host, (const char*)c->base[plane] + (size_t)which * d.lr_step * d.bpp, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, const int *ref_lowres, int merange,
+                         int method, int subme, int qp, x265amd_me_result *out)
+{
+    if (!c || !enc_lowres || !ref_lowres || n_pairs < 0)
+        return X265AMD_ERR_INVALID;
+    if (n_pairs == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 || qp < 0 || qp > 51 || merange < 0 || merange > 32767)
+        return fail(c, X265AMD_ERR_INVALID, "lookahead search parameter out of range");
+    std::vector<LookPair> hp(n_pairs);
+    const PlaneDesc *first = nullptr;
+    for (int i = 0; i < n_pairs; i++)
+    {
+        for (int id : { enc_lowres[i], ref_lowres[i] })
+        {
+            if (id < 0 || id >= MAX_PLANES || !c->used[id] || !c->h_planes[id].lr_step)
+                return fail(c, X265AMD_ERR_INVALID, "lookahead search needs half-resolution plane sets");
+            const PlaneDesc &d = c->h_planes[id];
+            if (!first)
+                first = &d;
+            if (d.width != first->width || d.height != first->height || d.stride != first->stride || d.bpp != first->bpp)
+                return fail(c, X265AMD_ERR_INVALID, "half-resolution sets of one call must share their geometry");
+        }
+        hp[i].enc_plane = enc_lowres[i];
+        hp[i].ref_plane = ref_lowres[i];
+    }
+    const int cu_w = first->width / 8, cu_h = first->height / 8;
+    const size_t n_res = (size_t)n_pairs * cu_w * cu_h;
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
+    if (int rc = ensure(c, c->look_results, n_res * sizeof(x265amd_me_result))) return rc;
+    if (int rc = ensure(c, c->look_progress, ((size_t)n_pairs * cu_h + 1) * sizeof(int))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // hp goes out of scope
+    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, ((size_t)n_pairs * cu_h + 1) * sizeof(int), c->stream));
+    if (int rc = record_start(c)) return rc;
+    if (c->timing)
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    int *progress = (int*)c->look_progress.p, *error = progress + (size_t)n_pairs * cu_h;
+    const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
+    const dim3 grid(n_pairs * cu_h), block(64);
+    if (first->bpp == 1)
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint8_t, 1, 64>>), grid, block, 0, c->stream, c->d_planes, cost,
+                           (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
+                           (x265amd_me_result*)c->look_results.p, progress, error, c->d_evals);
+    else
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint16_t, 1, 64>>), grid, block, 0, c->stream, c->d_planes, cost,
+                           (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
+                           (x265amd_me_result*)c->look_results.p, progress, error, c->d_evals);
+    HIPCHK(c, hipGetLastError());
+    if (c->timing)
+    {
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        c->timed_any = true;
+    }
+    if (!out)
+        return 0;
+    int h_err = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->look_results.p, n_res * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&h_err, error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_err)
+        return fail(c, X265AMD_ERR_HIP, "lookahead search: a CU row waited too long for the row below it");
+    return 0;
+}
+
+const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
+{
+    return c ? (const x265amd_me_result*)c->look_results.p : nullptr;
 }
 
 int x265amd_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x265amd_block_pair *pairs, int32_t *out)
