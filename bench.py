@@ -262,6 +262,26 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- lookahead path (rank 0 only, not part of `value`): half-resolution plane sets and whole-frame
+    # neighbour-predicted searches with the reference's lookahead settings (HEX, subme 1, merange 16, qp 12)
+    LOOK_PAIRS = 16
+    lr_enc, lr_ref = eng.lowres_create(enc_id), eng.lowres_create(ref_id)
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.lowres_update(lr_enc, enc_id)
+    eng.sync()
+    lowres_us = (time.perf_counter() - t0) / 50 * 1e6
+    look = {}
+    for n in (1, LOOK_PAIRS):
+        for _ in range(2):
+            eng.lookahead_me([lr_enc] * n, [lr_ref] * n, fetch=False)
+        eng.eval_count(reset=True)
+        eng.lookahead_me([lr_enc] * n, [lr_ref] * n, fetch=False)
+        look[n] = (eng.kernel_times()[1], eng.eval_count())
+    look_field = eng.lookahead_me([lr_enc], [lr_ref])[0]
+    _, _, _, look_cw, look_ch = eng.lowres_geometry(lr_enc)
+
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -307,9 +327,30 @@ def main():
                                      "unit": "T pixel-SAD/s", "frac": full_px_rate / sad_peak, "kernel_ms": k_full_ms,
                                      "search_kernel_ms": k_tail_ms,
                                      "peak_def": "%d CUs x %d lanes/clk x 4 px (v_sad_u8) x %.2f GHz" % (cus, SAD_LANES_PER_CLK_PER_CU, clk_hz / 1e9)}},
+        "lookahead": {"workload": "1080p 8-bit -> 960x544 half-resolution sets; whole-frame searches of %d x %d 8x8 CUs with the "
+                                  "neighbour-predicted MV chain, HEX + subme 1, merange 16, qp 12 (the reference's lookahead settings)"
+                                  % (look_cw, look_ch),
+                      "pairs_per_call": LOOK_PAIRS, "kernel_ms_per_call": look[LOOK_PAIRS][0],
+                      "frame_pairs_per_s": LOOK_PAIRS / (look[LOOK_PAIRS][0] * 1e-3),
+                      "value": look[LOOK_PAIRS][1] / (look[LOOK_PAIRS][0] * 1e-3), "unit": "evals/s",
+                      "single_pair_kernel_ms": look[1][0], "lowres_init_us_per_picture": lowres_us},
     }
 
     if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_ffi as F
+        if F.have_reference(8):
+            # the reference's C path on one host core: plane construction is its primitive + numpy borders
+            # (not timed), the search is its MotionEstimate driven in the lookahead's order
+            r8 = F.Reference(8)
+            g_lr, e4 = r8.lowres_init(enc_np)
+            _, r4 = r8.lowres_init(ref_np)
+            t0 = time.perf_counter()
+            cpu_field = r8.lookahead_me(e4, r4, g_lr.cu_w, g_lr.cu_h, 16, J.HEX, 1, 12)
+            cpu_dt = time.perf_counter() - t0
+            line["lookahead"]["cpu_baseline"] = {"value": look[1][1] / cpu_dt, "unit": "evals/s", "cores": 1, "kind": "reference",
+                                                 "ms_per_frame_pair": cpu_dt * 1e3, "sample": "one 1080p frame pair"}
+            line["lookahead"]["parity_ok"] = bool(np.array_equal(cpu_field, look_field))
         cb = cpu_baseline(enc_np, ref_np, hex_jobs, full_jobs)
         line["cpu_baseline"] = cb["hex"]
         line["cpu_baseline_full_search"] = cb["full"]

@@ -195,7 +195,7 @@ __device__ __forceinline__ void group_xy(int g, int w, int h, int &x, int &y)
 
 // ------------------------------------------------------------------ per-job state in LDS
 
-enum { PRED_INT = 0, PRED_H = 1, PRED_V = 2, PRED_HV = 3, PRED_LR = 4 };
+enum { PRED_INT = 0, PRED_H = 1, PRED_V = 2, PRED_HV = 3 };
 
 // Phase word of a candidate (JobState::frc).  Full-resolution reference: xf | yf << 2.  Half-resolution
 // set (subpelCompare's isLowres branch, encoder/motion.cpp:1112-1137): LR_FLAG | plane A | plane B << 2 |
@@ -238,12 +238,15 @@ struct JobState
     int32_t  frc[8];                // their fractional phases xf | yf << 2 (eval_any)
 };
 
-// LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64)
-template <typename PIX_, int NW_, int MAXG_>
+// LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64).
+// LR: the kernel also handles half-resolution reference sets (PlaneDesc::lr_step != 0); kernels
+// built without it are leaner and must not be given such references.
+template <typename PIX_, int NW_, int MAXG_, bool LR_ = false>
 struct JobLds
 {
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
+    static constexpr bool LR = LR_;
     // window bytes for 8-bit pixels: the square PU of the class with the full margin (long thin PUs get less margin)
     static constexpr int WIN_BYTES = (MAXG >= 1024 ? 8704 : MAXG >= 256 ? 4352 : 2560) * (int)sizeof(PIX);
 
@@ -770,7 +773,7 @@ struct Dev
     // element `ioff`.  `mode` is uniform: the switch is a scalar branch.
     template <bool LW>
     static __device__ __forceinline__ P4 pred4(const View &v, const Src &src, int mode, int off, int pitch, int ioff, int w,
-                                               int depth_rt, int xf, int yf, int lr)
+                                               int depth_rt, int xf, int yf)
     {
         constexpr int step = LW ? PB : 1;
         if (mode == PRED_INT)
@@ -778,26 +781,6 @@ struct Dev
             uint32_t d[2];
             src.template rd4_packed<LW>(off, d);
             return unpack4(d);
-        }
-        if (mode == PRED_LR)       // half-resolution reference: a half-pel plane, or the rounded mean of two
-        {                          // (encoder/motion.cpp:1114-1136); always read from the planes
-            const int step_lr = v.s->lrstep;
-            uint32_t a[2], b[2];
-            src.rd4_plane(off, (lr & 3) * step_lr, a);
-            if (!(lr & 0x10))
-                return unpack4(a);
-            src.rd4_plane(off + ((lr >> 5) & 1) + ((lr >> 6) & 1) * pitch, ((lr >> 2) & 3) * step_lr, b);
-            if (DW == 1)
-            {
-                a[0] = __builtin_amdgcn_lerp(a[0], b[0], 0x01010101u);     // per byte (a + b + 1) >> 1
-                return unpack4(a);
-            }
-            const P4 pa = unpack4(a), pb = unpack4(b);
-            P4 r;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                r.v[i] = (pa.v[i] + pb.v[i] + 1) >> 1;
-            return r;
         }
         const int depth = DW == 1 ? 8 : depth_rt;     // 8-bit planes: every shift and bound is a constant
         const int hr = 14 - depth;
@@ -888,15 +871,47 @@ struct Dev
     // the instruction footprint small.
     struct HvCache { int off, xf; bool valid; };    // which horizontal intermediate LDS holds (uniform)
 
+    // which accumulation a cost kind needs for this PU: 0 sad, 1 4x4 Hadamard (halved at the end),
+    // 2 8x8 Hadamard rounded per 8x8, 3 8x8 Hadamard rounded per 16x16 (common/pixel.cpp:652-826)
+    static __device__ __forceinline__ int accum_mode(int kind, int w, int h)
+    {
+        const bool m8 = ((w | h) & 7) == 0, m16 = ((w | h) & 15) == 0;
+        return kind == X265AMD_SAD ? 0 : (kind == X265AMD_SATD || !m8) ? 1 : (m16 ? 3 : 2);
+    }
+    // add one pass's differences d[4] of this lane: a0 per-lane partials, a1 sums already rounded per
+    // 16x16 (lane 63 only).  Executed by every lane (inactive ones with d = 0): the transforms cross lanes.
+    static __device__ __forceinline__ void accum(int am, const int *d, int lane, int &a0, int &a1)
+    {
+        if (am == 0)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                a0 += d[i] < 0 ? -d[i] : d[i];
+        }
+        else if (am == 1)
+            a0 += had4_partial(d, lane);
+        else
+        {
+            int sm = had8_partial(d, lane);
+            if (am == 3)
+            {
+                int s64 = wave_sum_last(sm);                             // sa8d16: one rounding per 16x16 (= one wave pass)
+                a1 += (lane == 63) ? ((s64 + 2) >> 2) : 0;
+            }
+            else
+            {
+                int s16 = sum16(sm);                                     // sa8d8: one rounding per 8x8
+                a0 += ((lane & 15) == 0) ? ((s16 + 2) >> 2) : 0;
+            }
+        }
+    }
+
     static __device__ __forceinline__ int cost_body(View &v, const Src &src, bool lw, int off, int pitch, int frac,
                                                     int kind, int par, HvCache &hc)
     {
         const int w = uni(v.s->w), h = uni(v.s->h), depth = v.s->depth;
-        const bool lr = (frac & LR_FLAG) != 0;
-        const int xf = lr ? 0 : frac & 3, yf = lr ? 0 : (frac >> 2) & 3;
-        const int mode = lr ? PRED_LR : (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
-        const bool m8 = ((w | h) & 7) == 0;
-        const bool m16 = ((w | h) & 15) == 0;
+        const int xf = frac & 3, yf = (frac >> 2) & 3;
+        const int mode = (xf ? PRED_H : 0) | (yf ? PRED_V : 0);
         int hv_row = 0;             // first intermediate row of this candidate
         if (mode == PRED_HV)
         {
@@ -910,8 +925,7 @@ struct Dev
                 hc.off = uoff; hc.xf = xf; hc.valid = true;
             }
         }
-        // which accumulation: 0 sad, 1 4x4 Hadamard (halved at the end), 2 8x8 with 8x8 rounding, 3 8x8 with 16x16 rounding
-        const int am = kind == X265AMD_SAD ? 0 : (kind == X265AMD_SATD || !m8) ? 1 : (m16 ? 3 : 2);
+        const int am = accum_mode(kind, w, h);
         int acc[2] = { 0, 0 };      // [0] per-lane partials, [1] sums already rounded per 16x16 (lane 63 only)
         for (int t = 0; t < v.T; t++)
         {
@@ -926,34 +940,13 @@ struct Dev
                     fd[1] = v.l->fenc[DW * g + 1];
                 const P4 f = unpack4(fd);
                 const int lo = off + gy * pitch + gx * (lw ? PB : 1);
-                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf, frac)
-                                : pred4<false>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf, frac);
+                const P4 r = lw ? pred4<true>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf)
+                                : pred4<false>(v, src, mode, lo, pitch, (gy + hv_row) * w + gx, w, depth, xf, yf);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     d[i] = f.v[i] - r.v[i];
             }
-            if (am == 0)
-            {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    acc[0] += d[i] < 0 ? -d[i] : d[i];
-            }
-            else if (am == 1)
-                acc[0] += had4_partial(d, v.lane);
-            else
-            {
-                int sm = had8_partial(d, v.lane);
-                if (am == 3)
-                {
-                    int s64 = wave_sum_last(sm);                             // sa8d16: one rounding per 16x16 (= one wave pass)
-                    acc[1] += (v.lane == 63) ? ((s64 + 2) >> 2) : 0;
-                }
-                else
-                {
-                    int s16 = sum16(sm);                                     // sa8d8: one rounding per 8x8
-                    acc[0] += ((v.lane & 15) == 0) ? ((s16 + 2) >> 2) : 0;
-                }
-            }
+            accum(am, d, v.lane, acc[0], acc[1]);
         }
         v.template job_sum<2>(acc, par);
         int tot = acc[0];
@@ -1025,8 +1018,81 @@ struct Dev
         return r;
     }
 
+    // N candidates against a half-resolution reference set (phase words with LR_FLAG): every
+    // candidate's plane reads are issued before the first cost is reduced, so a refinement round pays
+    // the memory latency once, and ONE cross-wave reduction serves all candidates.  Lane k receives
+    // the cost of candidate k in `res`.
+    template <int N>
+    static __device__ __forceinline__ void lr_batch(View &v, const Src &src, int kind, int par, int &res)
+    {
+        const int w = uni(v.s->w), h = uni(v.s->h), pitch = v.s->stride, step_lr = v.s->lrstep;
+        const int am = accum_mode(kind, w, h);
+        int offa[N], offb[N], adda[N], addb[N];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            const int off = v.s->pts[k], fr = uni(v.s->frc[k]);
+            const bool avg = (fr & 0x10) != 0;          // without averaging "B" is A again: (a + a + 1) >> 1 == a
+            offa[k] = off;
+            offb[k] = avg ? off + ((fr >> 5) & 1) + ((fr >> 6) & 1) * pitch : off;
+            adda[k] = (fr & 3) * step_lr;
+            addb[k] = (avg ? (fr >> 2) & 3 : fr & 3) * step_lr;
+        }
+        int acc[N];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            acc[k] = 0;
+        for (int t = 0; t < v.T; t++)
+        {
+            const int g = t * NT + v.tid;
+            const bool active = g < v.G;
+            const int gv = active ? v.l->gxy[g] : 0, lo = (gv >> 8) * pitch + (gv & 0xff);
+            uint32_t fd[2] = { 0, 0 };
+            if (active)
+            {
+                fd[0] = v.l->fenc[DW * g];
+                if (DW == 2)
+                    fd[1] = v.l->fenc[DW * g + 1];
+            }
+            const P4 f = unpack4(fd);
+            uint32_t a[N][2], b[N][2];
+#pragma unroll
+            for (int k = 0; k < N; k++)
+            {
+                src.rd4_plane(offa[k] + lo, adda[k], a[k]);
+                src.rd4_plane(offb[k] + lo, addb[k], b[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++)
+            {
+                P4 r;
+                if (DW == 1)
+                {
+                    a[k][0] = __builtin_amdgcn_lerp(a[k][0], b[k][0], 0x01010101u);     // per byte (a + b + 1) >> 1
+                    r = unpack4(a[k]);
+                }
+                else
+                {
+                    const P4 pa = unpack4(a[k]), pb = unpack4(b[k]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        r.v[i] = (pa.v[i] + pb.v[i] + 1) >> 1;
+                }
+                int d[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    d[i] = active ? f.v[i] - r.v[i] : 0;
+                accum(am, d, v.lane, acc[k], acc[k]);
+            }
+        }
+        v.template job_sum<N>(acc, par);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            res += (v.lane == k) ? (am == 1 ? acc[k] >> 1 : acc[k]) : 0;
+    }
+
     // eval_any: any cost kind, each candidate with its own phase (JobState::frc), one cost_body per
-    // candidate.
+    // candidate (half-resolution reference sets: one batch, lr_batch).
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_)
     {
         const int n = uni(n_), cflags = uni(cflags_), kind = uni(kind_);
@@ -1036,6 +1102,17 @@ struct Dev
         Src src(v, lw);
         int res = label_cost(v, n, cflags);     // lane k collects candidate k
         int par = (cflags & CF_PAR) ? 1 : 0;
+        if (L::LR && (uni(v.s->frc[0]) & LR_FLAG))
+        {
+            if (n == 1)      lr_batch<1>(v, src, kind, par, res);
+            else if (n <= 4) lr_batch<4>(v, src, kind, par, res);
+            else             lr_batch<8>(v, src, kind, par, res);
+            Res8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                r.c[k] = __builtin_amdgcn_readlane(res, k);
+            return r;
+        }
         HvCache hc = { 0, 0, false };
         for (int k = 0; k < n; k++)
         {
@@ -1124,7 +1201,8 @@ struct Wave
 
     // bind the PU: fill fenc / gxy / JobState.  (enc_x,enc_y) / (ref_x,ref_y): PU origin in the two planes.
     __device__ __forceinline__ void bind(L &lds_obj, const PlaneDesc &enc, const PlaneDesc &ref, int enc_x, int enc_y,
-                                         int ref_x, int ref_y, int w_, int h_, const uint16_t *cost_, int flags)
+                                         int ref_x, int ref_y, int w_, int h_, const uint16_t *cost_, int flags,
+                                         bool keep_slices = false)
     {
         l = (typename D::LP)&lds_obj;
         base = (uint32_t)(uintptr_t)l;
@@ -1135,7 +1213,10 @@ struct Wave
         ikind = X265AMD_SAD;
         jflags = flags;
         mvpx = mvpy = 0;
-        sliced = false;
+        // (keep_slices: the same context was bound before with the same cost table, whose LDS slice -
+        // independent of the predictor - is still valid)
+        if (!keep_slices)
+            sliced = false;
         wvalid = false;
         wx0 = wy0 = ww = wh = wpitch = 0;
         par = 0;
@@ -1149,8 +1230,8 @@ struct Wave
         s->stride = ref.stride; s->depth = ref.depth;
         s->w = w; s->h = h; s->G = G; s->T = (G + NT - 1) / NT;
         s->mvpx = 0; s->mvpy = 0;
-        s->sliced = 0;
-        lowres = ref.lr_step != 0;
+        s->sliced = sliced ? 1 : 0;
+        lowres = L::LR && ref.lr_step != 0;
         s->lrstep = (int32_t)ref.lr_step;
         const PIX *e = (const PIX*)enc.origin + (int64_t)enc_y * enc.stride + enc_x;
         D::post(base, D::OP_FILL, (int)(uint32_t)(uint64_t)e, (int)((uint64_t)e >> 32), enc.stride);
@@ -1180,7 +1261,7 @@ struct Wave
         mvpx = mvpx_;
         mvpy = mvpy_;
         s->mvpx = mvpx; s->mvpy = mvpy;
-        if (jflags & JF_NO_SLICES)
+        if ((jflags & JF_NO_SLICES) || sliced)
             return;
         sliced = true;
         s->sliced = 1;
@@ -1248,12 +1329,10 @@ struct Wave
         {
             const bool real = k < N && k < n;
             s->pts[k] = block_off(where, real ? sx[k < N ? k : 0] : sx[0], real ? sy[k < N ? k : 0] : sy[0]);
+            if (frac)
+                s->frc[k] = real ? frac[k < N ? k : 0] : frac[0];       // (entries >= n repeat candidate 0, like pts)
             if (k < N)
-            {
                 s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
-                if (frac)
-                    s->frc[k] = frac[k];
-            }
         }
         evals += (unsigned)n;
         Res8 r;
@@ -1265,7 +1344,8 @@ struct Wave
         }
         else
         {
-            const int cf = where | cflags | take_par(n);
+            // (a half-resolution batch reduces all its candidates at once)
+            const int cf = where | cflags | take_par((frac && lowres) ? 1 : n);
             if (!frac)
             {
 #pragma unroll

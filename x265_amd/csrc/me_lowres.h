@@ -72,46 +72,47 @@ __global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo
 // right to left; it may search CU (x, y) once the row below has finished CU x - 1, so the rows
 // form a wavefront two CUs apart and the result is the reference's, bit for bit.
 //
-// Hand-over between rows: the owner writes the CU's result, then release-stores its row's count of
-// finished CUs (device scope); the row above acquire-loads that count.  Row y waits only on row
-// y + 1, i.e. workgroup b only on workgroup b - 1 of the same pair, which was dispatched earlier:
-// the chain always makes progress.  A bounded spin guards against a lost predecessor.
+// Hand-over between rows: a CU's result is written with ONE 64-bit device-scope atomic store, and
+// the result array starts out filled with a word no search can produce (MV component 0x7fff, the
+// reference's own "not searched yet" mark, common/lowres.cpp:126-127): a reader polls the MV word
+// of the neighbour it needs with device-scope atomic loads until it differs.  No fences, hence no
+// cache write-backs or invalidations.  Row y waits only on row y + 1, i.e. workgroup b only on
+// workgroup b - 1 of the same pair, which was dispatched earlier: the chain always makes progress.
+// A bounded spin guards against a lost predecessor.
 struct LookPair { int32_t enc_plane, ref_plane; };
 
 constexpr int LOOK_SPIN_LIMIT = 1 << 24;
+constexpr int LOOK_UNSET = 0x7fff7fff;
 
 struct LookLeaf
 {
-    // Wait until *count >= need (or the spin limit); 0 on success.  Out of line: the kernel body keeps
-    // only uniform control flow.
-    static __device__ __noinline__ int wait_count(const int *count, int need_)
+    // MV words (mvy << 16 | mvx & 0xffff) of the lower-left, lower and lower-right neighbours
+    // (`below` - 1, `below`, `below` + 1; bit k of `mask`: neighbour k exists), once they are all
+    // there: lanes 0..2 poll one each.  Returned per lane; LOOK_UNSET in a lane that gave up at the
+    // spin limit, 0 for an absent neighbour.  Out of line: the kernel body keeps only uniform
+    // control flow.
+    static __device__ __noinline__ int wait_mv3(const x265amd_me_result *below, int mask_)
     {
-        const int need = uni(need_);
+        const int mask = uni(mask_), lane = lane_id();
+        const bool mine = lane < 3 && ((mask >> lane) & 1);
+        int w = mine ? LOOK_UNSET : 0;
         for (int spin = 0; spin < LOOK_SPIN_LIMIT; spin++)
         {
-            const int c = uni(__hip_atomic_load(count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-            if (c >= need)
-                return 0;
-            __builtin_amdgcn_s_sleep(4);
+            if (mine)
+                w = __hip_atomic_load((const int*)(below + (lane - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(w == LOOK_UNSET) == 0)
+                break;
+            __builtin_amdgcn_s_sleep(2);
         }
-        return 1;
+        return w;
     }
-    // MV word (mvy << 16 | mvx & 0xffff) of a finished CU of another row
-    static __device__ __noinline__ int load_mv(const x265amd_me_result *r)
-    {
-        return uni(__hip_atomic_load((const int*)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    // one lane publishes a CU's result and then the row's new count
-    static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost, int *count, int done)
+    // one lane publishes a CU's result
+    static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost)
     {
         if (threadIdx.x == 0)
         {
-            x265amd_me_result r;
-            r.mvx = (int16_t)mvx;
-            r.mvy = (int16_t)mvy;
-            r.cost = cost;
-            *out = r;
-            __hip_atomic_store(count, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v = ((unsigned long long)(uint32_t)cost << 32) | (uint32_t)((mvy << 16) | (mvx & 0xffff));
+            __hip_atomic_store((unsigned long long*)out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     static __device__ __noinline__ void finish(unsigned long long *evals, unsigned n_evals, int *error, int failed)
@@ -139,8 +140,7 @@ __device__ __forceinline__ int look_median(int a, int b, int c)
 template <class L>
 __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
                                                   int cu_w, int cu_h, int merange, int method, int subme, int qp, int flags,
-                                                  x265amd_me_result *out, int *progress, int *error,
-                                                  unsigned long long *evals)
+                                                  x265amd_me_result *out, int *error, unsigned long long *evals)
 {
     static_assert(L::NW == 1, "one wavefront per CU row");
     __shared__ __align__(16) L lds;
@@ -149,21 +149,36 @@ __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const
     const PlaneDesc &enc = planes[pairs[pair].enc_plane];
     const PlaneDesc &ref = planes[pairs[pair].ref_plane];
     x265amd_me_result *res = out + (size_t)pair * cu_w * cu_h;
-    int *count = progress + (size_t)pair * cu_h;
     const bool have_b = cuy < cu_h - 1;
     unsigned n_evals = 0;
     int failed = 0;
     int right = 0;                                                       // MV word of the CU searched last (right neighbour)
+    Wave<L> W;
+    W.sliced = false;
+#ifdef XA_PROFILE
+    long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 
     for (int cux = cu_w - 1; cux >= 0; cux--)
     {
         const bool have_r = cux < cu_w - 1;
+        // the row below must have finished its CUs down to cux - 1 (it walks right to left, so
+        // that one is the last of the three lower neighbours to appear)
+        const x265amd_me_result *below = res + (size_t)(cuy + 1) * cu_w + cux;
+        int w_b = 0, w_bl = 0, w_br = 0;
+        W.stamp(0);
+        // (the PU is cached while the neighbours may still be busy)
+        W.bind(lds, enc, ref, 8 * cux, 8 * cuy, 8 * cux, 8 * cuy, 8, 8, cost, flags, true);
+        W.stamp(1);
         if (have_b)
         {
-            int need = cu_w - cux + 1;
-            need = need > cu_w ? cu_w : need;
-            failed |= uni(LookLeaf::wait_count(count + cuy + 1, need));     // (results of calls arrive in vector registers)
+            const int v = LookLeaf::wait_mv3(below, (cux > 0 ? 1 : 0) | 2 | (have_r ? 4 : 0));
+            w_bl = __builtin_amdgcn_readlane(v, 0);
+            w_b = __builtin_amdgcn_readlane(v, 1);
+            w_br = __builtin_amdgcn_readlane(v, 2);
+            failed |= (w_bl == LOOK_UNSET) | (w_b == LOOK_UNSET) | (w_br == LOOK_UNSET);
         }
+        W.stamp(6);
         // slicetype.cpp:385-405: candidates right, below, below-left, below-right (those that exist),
         // appended in that order; unused entries 0 and 2 are zero vectors
         int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, numc = 0;
@@ -181,11 +196,10 @@ __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const
                 numc++;
             }
         };
-        const x265amd_me_result *below = res + (size_t)(cuy + 1) * cu_w + cux;
         push(have_r, right);
-        push(have_b, have_b ? uni(LookLeaf::load_mv(below)) : 0);
-        push(have_b && cux > 0, (have_b && cux > 0) ? uni(LookLeaf::load_mv(below - 1)) : 0);
-        push(have_b && have_r, (have_b && have_r) ? uni(LookLeaf::load_mv(below + 1)) : 0);
+        push(have_b, w_b);
+        push(have_b && cux > 0, w_bl);
+        push(have_b && have_r, w_br);
 
         JobRegs j;
         j.pu_x = 8 * cux;
@@ -215,16 +229,29 @@ __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const
             j.qmvp_y = look_median(cy[0], cy[1], cy[2]);
         }
 
-        Wave<L> W;
-        W.bind(lds, enc, ref, j.pu_x, j.pu_y, j.pu_x, j.pu_y, 8, 8, cost, flags);
         Search<L> S(W, j);
         int ox, oy;
         const int c = S.run(nullptr, 0, ox, oy);
         n_evals += W.evals;
         right = (oy << 16) | (ox & 0xffff);
-        LookLeaf::publish(res + (size_t)cuy * cu_w + cux, ox, oy, c, count + cuy, cu_w - cux);
+        LookLeaf::publish(res + (size_t)cuy * cu_w + cux, ox, oy, c);
+#ifdef XA_PROFILE       // developer aid: clocks per phase, summed over the CUs of every 8th row
+        W.stamp(7);
+        if ((blockIdx.x & 7) == 0)
+        {
+            const int from[8] = { 0, 1, 6, 2, 3, 4, 5, 0 }, to[8] = { 1, 6, 2, 3, 4, 5, 7, 7 };
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                prof[k] += W.tstamp[to[k]] - W.tstamp[from[k]];
+        }
+#endif
     }
     LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
+#ifdef XA_PROFILE
+    if (threadIdx.x == 0 && (blockIdx.x & 7) == 0)
+        for (int k = 0; k < 8; k++)
+            atomicAdd(evals + EVAL_SLOTS * 16 + 8 + k, (unsigned long long)prof[k]);
+#endif
 }
 
 } // namespace xa

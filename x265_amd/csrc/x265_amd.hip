@@ -276,18 +276,19 @@ int join_streams(x265amd_ctx *c, int lanes)
 
 // idx[cls] / cnt[cls]: device index lists of the job classes (idx == NULL: every block looks at its own
 // job and the kernels of the other classes skip it)
-template <typename PIX>
+// (LR: some reference of the batch is a half-resolution set)
+template <typename PIX, bool LR>
 void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *d_jobs, const int *const *idx, const int *cnt,
                     const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool side_by_side)
 {
     // the large PUs first: they are the long-running workgroups
     int k = 0;
     if (cnt[2] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256>>), dim3(cnt[1]), dim3(256), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256, LR>>), dim3(cnt[1]), dim3(256), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
 }
 
 int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
@@ -312,10 +313,17 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
     const int lanes = idx_base ? (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) : 1;
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
-    if (bpp == 1)
-        launch_classes<uint8_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
+    bool lr = false;
+    for (int i = 0; i < P.n_refs; i++)
+        lr = lr || c->h_planes[P.ref_planes[i]].lr_step != 0;
+    if (bpp == 1 && !lr)
+        launch_classes<uint8_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
+    else if (bpp == 1)
+        launch_classes<uint8_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
+    else if (!lr)
+        launch_classes<uint16_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else
-        launch_classes<uint16_t>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
+        launch_classes<uint16_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     if (lanes > 1)
         if (int rc = join_streams(c, lanes)) return rc;
     HIPCHK(c, hipGetLastError());
@@ -1012,24 +1020,25 @@ int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, con
     if (int rc = sync_planes(c)) return rc;
     if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
     if (int rc = ensure(c, c->look_results, n_res * sizeof(x265amd_me_result))) return rc;
-    if (int rc = ensure(c, c->look_progress, ((size_t)n_pairs * cu_h + 1) * sizeof(int))) return rc;
+    if (int rc = ensure(c, c->look_progress, sizeof(int))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));          // hp goes out of scope
-    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, ((size_t)n_pairs * cu_h + 1) * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->look_results.p, LOOK_UNSET, n_res * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    int *progress = (int*)c->look_progress.p, *error = progress + (size_t)n_pairs * cu_h;
+    int *error = (int*)c->look_progress.p;
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
     const dim3 grid(n_pairs * cu_h), block(64);
     if (first->bpp == 1)
-        hipLaunchKernelGGL((k_lookahead<JobLds<uint8_t, 1, 64>>), grid, block, 0, c->stream, c->d_planes, cost,
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint8_t, 1, 64, true>>), grid, block, 0, c->stream, c->d_planes, cost,
                            (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
-                           (x265amd_me_result*)c->look_results.p, progress, error, c->d_evals);
+                           (x265amd_me_result*)c->look_results.p, error, c->d_evals);
     else
-        hipLaunchKernelGGL((k_lookahead<JobLds<uint16_t, 1, 64>>), grid, block, 0, c->stream, c->d_planes, cost,
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint16_t, 1, 64, true>>), grid, block, 0, c->stream, c->d_planes, cost,
                            (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
-                           (x265amd_me_result*)c->look_results.p, progress, error, c->d_evals);
+                           (x265amd_me_result*)c->look_results.p, error, c->d_evals);
     HIPCHK(c, hipGetLastError());
     if (c->timing)
     {
@@ -1236,6 +1245,9 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
         const unsigned long long *q = &t[(size_t)EVAL_SLOTS * 16];
         fprintf(stderr, "phase clocks: bind %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu\n",
                 q[0], q[1], q[2], q[3], q[4], q[5]);
+        if (q[15])
+            fprintf(stderr, "lookahead rows (sampled), clocks: cache PU %llu  wait for the row below %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu  | whole CU loop %llu\n",
+                    q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]);
         unsigned long long fp[8], zero[8] = { 0 };
         HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_full_prof), sizeof(fp)));
         if (fp[4])
