@@ -88,6 +88,32 @@ def test_lookahead_frames_match_oracle(eng, oracle, bits, w, h):
         eng.release_plane(p)
 
 
+def test_mixed_reference_kinds_in_one_batch(eng, oracle):
+    """jobs against a half-resolution set and against an ordinary plane of the same geometry in one
+    batch: the kernels built for half-resolution sets must also serve full-resolution references"""
+    fr = G.lowres_source_frames(8)
+    cpu = [oracle.lowres_init(f) for f in fr]
+    g = cpu[0][0]
+    src = [eng.upload_plane(f) for f in fr]
+    lr = [eng.lowres_create(s) for s in src]
+    # the F plane of frame 1 uploaded again as an ordinary plane (same stride as the set)
+    plain = eng.upload_plane(np.ascontiguousarray(cpu[1][1][0]))
+    jobs = G.lowres_jobs(g, 8)
+    jobs["ref_idx"] = np.arange(len(jobs)) % 2
+    got = eng.search(lr[0], [lr[1], plain], jobs)
+    exp = np.zeros(len(jobs), dtype=got.dtype)
+    a = jobs["ref_idx"] == 0
+    ja, jb = jobs[a].copy(), jobs[~a].copy()
+    ja["ref_idx"] = 0
+    jb["ref_idx"] = 0
+    exp[a] = oracle.search(cpu[0][1][0], [cpu[1][1]], ja, lowres=True)[0]
+    exp[~a] = oracle.search(cpu[0][1][0], [cpu[1][1][0]], jb)[0]
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    for p in lr + src + [plain]:
+        eng.release_plane(p)
+
+
 def test_lowres_argument_checks(eng):
     from x265_amd.api import X265AmdError
     fr = synth.make_sequence(64, 64, 1, seed=3)

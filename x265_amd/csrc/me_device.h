@@ -217,7 +217,8 @@ enum   // per-call flags of the pixel functions
     CF_WINDOW  = 1,                 // candidate offsets address the LDS window (bytes); else the plane (pixels)
     CF_NOTRUNC = 2,                 // do not truncate the sum of the two MV-cost entries to 16 bits
     CF_PAR     = 4,                 // parity of the (first) cross-wave reduction slot to use
-    CF_NOMV    = 8                  // do not add MV costs
+    CF_NOMV    = 8,                 // do not add MV costs
+    CF_NOMV0   = 16                 // do not add the MV cost of candidate 0
 };
 
 // Job scalars the out-of-line pixel functions read.  Written by the job's leader wave only, and only
@@ -959,7 +960,7 @@ struct Dev
     static __device__ __forceinline__ int label_cost(const View &v, int n, int cflags)
     {
         int mv = 0;
-        if (!(cflags & CF_NOMV) && v.lane < n)
+        if (!(cflags & CF_NOMV) && v.lane < n && !((cflags & CF_NOMV0) && v.lane == 0))
         {
             const int lb = v.s->lbl[v.lane];
             const int dx = (int16_t)((int16_t)lb - v.s->mvpx), dy = (int16_t)((lb >> 16) - v.s->mvpy);
@@ -1408,7 +1409,7 @@ struct Wave
     }
     // the same for the first n of 8 q-pel positions at once, each plus its MV cost: one refinement
     // round (motion.cpp:801-845) in a single call
-    __device__ __forceinline__ void subpel_cost8(int n, const int *qx, const int *qy, int kind, int *out)
+    __device__ __forceinline__ void subpel_cost8(int n, const int *qx, const int *qy, int kind, int *out, int cflags = 0)
     {
         int cx[8], cy[8], fr[8];
 #pragma unroll
@@ -1417,7 +1418,7 @@ struct Wave
             cx[k] = qx[k] >> 2; cy[k] = qy[k] >> 2;
             fr[k] = phase(qx[k], qy[k]);
         }
-        eval_n<8>(n, cx, cy, qx, qy, kind, fr, 0, out);
+        eval_n<8>(n, cx, cy, qx, qy, kind, fr, cflags, out);
     }
 
     // plain block cost against the block at the reference origin

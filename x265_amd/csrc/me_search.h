@@ -329,6 +329,94 @@ struct Search
         }
     }
 
+    // The predictor phase (motion.cpp:302-342) with every candidate priced in ONE evaluation call:
+    // the predictor, its full-pel rounding, the zero vector and the caller's candidates do not depend
+    // on one another's costs, only the bookkeeping does, and that is replayed afterwards in the
+    // reference's order.  Used by the kernels for half-resolution references, whose evaluations are
+    // latency-bound plane reads.  Sets bmx / bmy / bcost; returns bprecost.
+    __device__ __forceinline__ int predictors_batched(int pmx, int pmy, int &bprex, int &bprey,
+                                                      int qminx, int qminy, int qmaxx, int qmaxy)
+    {
+        auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };
+        const bool sub = ((pmx | pmy) & 3) != 0, nz = pmx || pmy;
+        bmx = XA_S16(XA_S16(pmx + 2) >> 2);
+        bmy = XA_S16(XA_S16(pmy + 2) >> 2);
+        // dense candidate list (static indices only: everything stays in scalar registers)
+        int qx[8], qy[8], n = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            qx[k] = qy[k] = 0;
+        auto push = [&](bool use, int x, int y)
+        {
+            int at = -1;
+            if (use)
+            {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (n == k)
+                    {
+                        qx[k] = x;
+                        qy[k] = y;
+                    }
+                at = n++;
+            }
+            return at;
+        };
+        push(true, pmx, pmy);
+        const int k_round = push(sub, XA_S16(bmx << 2), XA_S16(bmy << 2));
+        const int k_zero = push(nz, 0, 0);
+        int cmx[X265AMD_MAX_MVC], cmy[X265AMD_MAX_MVC], k_mvc[X265AMD_MAX_MVC];
+#pragma unroll
+        for (int i = 0; i < X265AMD_MAX_MVC; i++)
+        {
+            cmx[i] = clipq(j.mvc[i][0], qminx, qmaxx);
+            cmy[i] = clipq(j.mvc[i][1], qminy, qmaxy);
+            k_mvc[i] = push(i < j.numc && (cmx[i] || cmy[i]) && !(cmx[i] == pmx && cmy[i] == pmy), cmx[i], cmy[i]);
+        }
+        int c[8];
+        W.subpel_cost8(n, qx, qy, W.ikind, c, CF_NOMV0);      // the predictor itself carries no MV cost (motion.cpp:305)
+        auto at = [&](int k)
+        {
+            int r = c[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++)
+                r = (k == i) ? c[i] : r;
+            return r;
+        };
+        int bprecost = c[0];
+        bcost = bprecost;
+        if (sub)
+            bcost = at(k_round);
+        if (nz)
+        {
+            const int cz = at(k_zero);
+            if (cz < bcost)
+            {
+                bcost = cz;
+                bmx = bmy = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X265AMD_MAX_MVC; i++)
+        {
+            if (k_mvc[i] < 0)
+                continue;
+            if (cmx[i] == bprex && cmy[i] == bprey)
+            {
+                W.evals--;              // the reference skips a candidate equal to the best so far (motion.cpp:325)
+                continue;
+            }
+            const int cc = at(k_mvc[i]);
+            if (cc < bprecost)
+            {
+                bprecost = cc;
+                bprex = cmx[i];
+                bprey = cmy[i];
+            }
+        }
+        return bprecost;
+    }
+
     // ---------------------------------------------------------------- the search
     __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
     {
@@ -343,35 +431,41 @@ struct Search
         // predictor phase (motion.cpp:302-342)
         int pmx = clipq(j.qmvp_x, qminx, qmaxx), pmy = clipq(j.qmvp_y, qminy, qmaxy);
         int bprex = pmx, bprey = pmy;
-        int bprecost = W.subpel_cost(pmx, pmy, W.ikind, false);          // no mvcost term (motion.cpp:305)
-        bmx = XA_S16(XA_S16(pmx + 2) >> 2);
-        bmy = XA_S16(XA_S16(pmy + 2) >> 2);
-        bcost = bprecost;
-        if ((pmx | pmy) & 3)
-            bcost = W.cost_fpel(bmx, bmy);
-        if (pmx || pmy)
+        int bprecost;
+        if (L::LR)
+            bprecost = predictors_batched(pmx, pmy, bprex, bprey, qminx, qminy, qmaxx, qmaxy);
+        else
         {
-            int c = W.cost_fpel(0, 0);
-            if (c < bcost)
+            bprecost = W.subpel_cost(pmx, pmy, W.ikind, false);      // no mvcost term (motion.cpp:305)
+            bmx = XA_S16(XA_S16(pmx + 2) >> 2);
+            bmy = XA_S16(XA_S16(pmy + 2) >> 2);
+            bcost = bprecost;
+            if ((pmx | pmy) & 3)
+                bcost = W.cost_fpel(bmx, bmy);
+            if (pmx || pmy)
             {
-                bcost = c;
-                bmx = bmy = 0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < X265AMD_MAX_MVC; i++)
-        {
-            if (i >= j.numc)
-                break;
-            int mx = clipq(j.mvc[i][0], qminx, qmaxx), my = clipq(j.mvc[i][1], qminy, qmaxy);
-            if ((mx || my) && !(mx == pmx && my == pmy) && !(mx == bprex && my == bprey))
-            {
-                int c = W.subpel_cost(mx, my, W.ikind, true);
-                if (c < bprecost)
+                int c = W.cost_fpel(0, 0);
+                if (c < bcost)
                 {
-                    bprecost = c;
-                    bprex = mx;
-                    bprey = my;
+                    bcost = c;
+                    bmx = bmy = 0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < X265AMD_MAX_MVC; i++)
+            {
+                if (i >= j.numc)
+                    break;
+                int mx = clipq(j.mvc[i][0], qminx, qmaxx), my = clipq(j.mvc[i][1], qminy, qmaxy);
+                if ((mx || my) && !(mx == pmx && my == pmy) && !(mx == bprex && my == bprey))
+                {
+                    int c = W.subpel_cost(mx, my, W.ikind, true);
+                    if (c < bprecost)
+                    {
+                        bprecost = c;
+                        bprex = mx;
+                        bprey = my;
+                    }
                 }
             }
         }
