@@ -79,6 +79,19 @@ int main(int argc, char **argv)
         prim.sad_x4[27](e0, r0, r0 + 1, r0 + 2, r0 + 3, stride, res);   // PARTITION_16x16 == 27; fenc stride is 64 by contract
         printf("prim %d %d %d %d %d\n", prim.sad[27](e0, stride, r0 + 5, stride), prim.satd[27](e0, stride, r0 + 5, stride),
                prim.sa8d_inter[27](e0, stride, r0 + 5, stride), res[0], res[3]);
+        // (5) lookahead: half-resolution sets of both pictures, one whole-frame search, a few CUs printed
+        if (M >= 16)
+        {
+            x265amd::Lowres le = ctx.createLowres(pe), lf = ctx.createLowres(pr);
+            x265amd::Lookahead look(ctx);
+            const x265amd::Lowres *fe[1] = { &le }, *ff[1] = { &lf };
+            const std::vector<x265amd_me_result> &f = look.estimateFrameMotion(fe, ff, 1);
+            printf("look %d %d %d\n", le.widthInCU, le.heightInCU, (int)f.size());
+            for (size_t i = 0; i < f.size(); i++)
+                printf("cu %d %d %d %d\n", (int)i, f[i].mvx, f[i].mvy, f[i].cost);
+            ctx.releasePlane(le);
+            ctx.releasePlane(lf);
+        }
         ctx.releasePlane(pe);
         ctx.releasePlane(pr);
     }

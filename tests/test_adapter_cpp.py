@@ -59,3 +59,13 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
     exp3 = [oracle.cmp(k, p16, flat0, o0, stride, flat1, o0 + 5, stride) for k in (0, 1, 2)]
     x4 = oracle.sad_xn(4, p16, flat0, o0, flat1, [o0, o0 + 1, o0 + 2, o0 + 3], stride)
     assert [int(v) for v in prim[1:]] == exp3 + [int(x4[0]), int(x4[3])]
+    # (5) lookahead mirror: the whole-frame field of the half-resolution pair
+    g, e4 = oracle.lowres_init(fr[0])
+    _, r4 = oracle.lowres_init(fr[1])
+    exp, _ = oracle.lookahead_me(e4, r4, g.cu_w, g.cu_h, 16, J.HEX, 1, 12)
+    look = [l for l in lines if l[0] == "look"][0]
+    assert [int(v) for v in look[1:]] == [g.cu_w, g.cu_h, g.cu_w * g.cu_h]
+    cus = [l for l in lines if l[0] == "cu"]
+    assert len(cus) == len(exp)
+    for l, ex in zip(cus, exp):
+        assert (int(l[2]), int(l[3]), int(l[4])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"])), l

@@ -41,6 +41,14 @@ struct ReferencePlanes
     int lumaStride;
 };
 
+// Lowres (common/lowres.h:41-72), picture part: the F/H/V/C half-resolution planes live on the device;
+// as a search reference it behaves as ReferencePlanes with isLowres set
+struct Lowres : ReferencePlanes
+{
+    int width = 0, lines = 0;               // rounded up to whole 8x8 CUs (lowres.cpp:44-46)
+    int widthInCU = 0, heightInCU = 0;      // slicetype.cpp:74-75
+};
+
 class Context
 {
 public:
@@ -66,6 +74,20 @@ public:
         return r;
     }
     void releasePlane(const ReferencePlanes &p) { check(x265amd_plane_release(m_ctx, p.plane_id)); }
+
+    // Lowres::create + Lowres::init (common/lowres.cpp:30-58, 109-186): the half-resolution plane set
+    // of an uploaded picture (margins holding replicated borders), built on the device
+    Lowres createLowres(const ReferencePlanes &src)
+    {
+        Lowres l;
+        check(x265amd_lowres_create(m_ctx, src.plane_id, &l.plane_id));
+        intptr_t stride = 0;
+        check(x265amd_lowres_geometry(m_ctx, l.plane_id, &l.width, &l.lines, &stride, &l.widthInCU, &l.heightInCU));
+        l.lumaStride = (int)stride;
+        return l;
+    }
+    // Lowres::init for the next picture held by an existing set
+    void initLowres(const Lowres &l, const ReferencePlanes &src) { check(x265amd_lowres_update(m_ctx, l.plane_id, src.plane_id)); }
 
     void check(int rc) const
     {
@@ -180,6 +202,37 @@ private:
     std::vector<x265amd_me_job> m_jobs;
     std::vector<int> m_refs;
     std::vector<x265amd_me_result> m_results;
+};
+
+// The motion-search part of Lookahead::estimateFrameCost / estimateCUCost (encoder/slicetype.cpp:283-410)
+// with the reference's lookahead settings (slicetype.cpp:70-73).
+class Lookahead
+{
+public:
+    explicit Lookahead(Context &ctx, int qp = 12) : m_ctx(ctx), m_qp(qp) {}
+
+    // Search frame `fenc` against `fref` for every listed pair; field[pair * cuCount + cux + cuy * widthInCU]
+    // holds what the reference stores in lowresMvs / lowresMvCosts (slicetype.cpp:407).
+    const std::vector<x265amd_me_result> &estimateFrameMotion(const Lowres *const *fenc, const Lowres *const *fref, int pairs)
+    {
+        std::vector<int> e(pairs), r(pairs);
+        for (int i = 0; i < pairs; i++)
+        {
+            e[i] = fenc[i]->plane_id;
+            r[i] = fref[i]->plane_id;
+        }
+        m_field.resize(pairs ? (size_t)pairs * fenc[0]->widthInCU * fenc[0]->heightInCU : 0);
+        if (pairs)
+            m_ctx.check(x265amd_lookahead_me(m_ctx.get(), pairs, e.data(), r.data(), merange, X265AMD_HEX, 1, m_qp, m_field.data()));
+        return m_field;
+    }
+
+    int merange = 16;
+
+private:
+    Context &m_ctx;
+    int m_qp;
+    std::vector<x265amd_me_result> m_field;
 };
 
 // Overwrite the ME-related slots of a primitive table laid out like the reference's
