@@ -145,7 +145,9 @@ typedef struct x265amd_me_result
     int32_t cost;                       /* return value of motionEstimate() */
 } x265amd_me_result;
 
-/* jobs / out in host memory; blocks until the results are in `out` */
+/* jobs / out in host memory; blocks until the results are in `out`.  X265AMD_ERR_RANGE if a job's
+ * bounds (+3 pixels of pattern overshoot, +3/+4 of filter apron) leave the reference plane's margins;
+ * the device-array and job-list forms below do not check (the kernels clamp addresses) */
 int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                             const x265amd_me_job *jobs, int n, x265amd_me_result *out);
 

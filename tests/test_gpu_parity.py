@@ -284,3 +284,22 @@ def test_errors_are_reported(eng):
     assert len(empty) == 0
     for i in ids:
         eng.release_plane(i)
+
+
+def test_search_window_outside_margins_is_rejected(eng):
+    """the host batch call refuses jobs whose bounds (plus overshoot and filter apron) leave the plane"""
+    from x265_amd.api import X265AmdError
+    fr = synth.make_sequence(128, 128, 2, seed=12)
+    ids = [eng.upload_plane(f) for f in fr]
+    ok = J.make_jobs(128, 128, [0], [0], 16, 16, method=J.HEX, subme=5, merange=64, qp=30)
+    eng.search(ids[0], [ids[1]], ok)                   # the encoder's own rule stays inside (71 + 3 + 4 <= 80)
+    bad = ok.copy()
+    bad["mvmin_x"] = -75
+    with pytest.raises(X265AmdError, match="-5"):
+        eng.search(ids[0], [ids[1]], bad)
+    bad = ok.copy()
+    bad["pu_x"] = 128 + 80 - 8
+    with pytest.raises(X265AmdError, match="-5"):
+        eng.search(ids[0], [ids[1]], bad)
+    for i in ids:
+        eng.release_plane(i)

@@ -1122,6 +1122,29 @@ static int validate_jobs(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int 
     return 0;
 }
 
+// Every block a job can evaluate must lie inside the padded planes, as in the reference: the
+// search bounds, plus the 3 pixels a pattern may step beyond them before its range check, plus the
+// 8-tap filter's apron of 3 pixels before and 4 behind the block (encoder/motion.cpp:364,407,625;
+// common/ipfilter.cpp).  (The kernels clamp addresses, so a violation would not fault: it would
+// silently measure other pixels than the reference.)
+static int check_job_ranges(x265amd_ctx *c, int enc_plane, const int *ref_planes, const x265amd_me_job *jobs, int n)
+{
+    const PlaneDesc &e = c->h_planes[enc_plane];
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_me_job &j = jobs[i];
+        const PlaneDesc &r = c->h_planes[ref_planes[j.ref_idx]];
+        if (j.pu_x < -e.margin_x || j.pu_y < -e.margin_y || j.pu_x + j.w > e.width + e.margin_x || j.pu_y + j.h > e.height + e.margin_y)
+            return fail(c, X265AMD_ERR_RANGE, "PU outside the padded encoder plane");
+        if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
+            continue;           // empty range: only the clipped predictors are measured, at the clamped bounds
+        if (j.pu_x + j.mvmin_x - 6 < -r.margin_x || j.pu_y + j.mvmin_y - 6 < -r.margin_y ||
+            j.pu_x + j.w + j.mvmax_x + 7 > r.width + r.margin_x || j.pu_y + j.h + j.mvmax_y + 7 > r.height + r.margin_y)
+            return fail(c, X265AMD_ERR_RANGE, "a job's search window reaches outside the reference plane's margins");
+    }
+    return 0;
+}
+
 int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
                             const x265amd_me_job *jobs, int n, x265amd_me_result *out)
 {
@@ -1134,6 +1157,7 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     bool any_full = false;
     if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
+    if (int rc = check_job_ranges(c, enc_plane, ref_planes, jobs, n)) return rc;
     if (int rc = sync_planes(c)) return rc;
     x265amd_joblist *L = new x265amd_joblist;
     int rc = joblist_build(c, L, jobs, n, c->h_planes[enc_plane].bpp);
