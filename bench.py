@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--full-steps", type=int, default=10)
+    ap.add_argument("--only-primary", action="store_true",
+                    help="run only the HEX+subme5 leg `value` is quoted on (for profiler runs: every launch of the "
+                         "search kernels then belongs to that leg) and print a reduced line")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +223,19 @@ def main():
     # algorithmic HBM bytes of one launch: enc plane + ref plane read once, jobs read, results written
     alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
     achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
+
+    if args.only_primary:
+        if rank == 0:
+            print(json.dumps({"metric": "ME block-cost evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                              "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                                           "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                              "note": "reduced line of --only-primary"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- the same frame with the diamond search (the other method BASELINE configs[1] names) ----
     dia_jobs = hex_jobs.copy()
