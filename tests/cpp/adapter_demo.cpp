@@ -92,6 +92,32 @@ int main(int argc, char **argv)
             ctx.releasePlane(le);
             ctx.releasePlane(lf);
         }
+        // (6) motion field planned ahead of the call sites: a row of 16x16 PUs with foreseen predictors;
+        //     identical requests are served from the field, a request with another predictor is searched
+        {
+            x265amd::MotionField field(ctx);
+            me.setSearchMethod(3);
+            me.setSubpelRefine(3);
+            for (int x = 0; x + 16 <= W; x += 16)
+            {
+                me.setSourcePUxy(x, 48, 16, 16);
+                x265amd::MV c[1] = { x265amd::MV((int16_t)(x / 8), 2) };
+                field.add(pr, me.plan(x265amd::MV(-20, -20), x265amd::MV(20, 20), x265amd::MV(4, (int16_t)-(x / 16)), 1, c, 20));
+            }
+            field.run(pe);
+            me.attachField(&field);
+            for (int x = 0; x + 16 <= W; x += 16)
+            {
+                me.setSourcePUxy(x, 48, 16, 16);
+                x265amd::MV c[1] = { x265amd::MV((int16_t)(x / 8), 2) }, out;
+                bool foreseen = (x / 16) % 3 != 2;       // every third request arrives with another predictor
+                x265amd::MV mvp(4, (int16_t)(foreseen ? -(x / 16) : 7));
+                int cost = me.motionEstimate(&pr, x265amd::MV(-20, -20), x265amd::MV(20, 20), mvp, 1, c, 20, out);
+                printf("field %d %d %d %d %d\n", x, foreseen ? 1 : 0, out.x, out.y, cost);
+            }
+            printf("fieldstats %u %u %d\n", field.hits(), field.misses(), (int)field.size());
+            me.attachField(NULL);
+        }
         ctx.releasePlane(pe);
         ctx.releasePlane(pr);
     }

@@ -69,3 +69,18 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
     assert len(cus) == len(exp)
     for l, ex in zip(cus, exp):
         assert (int(l[2]), int(l[3]), int(l[4])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"])), l
+    # (6) motion field planned ahead: hits return the planned search's result, misses are searched on the spot;
+    #     either way the answer is the oracle's for the arguments actually passed
+    rows = [l for l in lines if l[0] == "field"]
+    assert len(rows) == W // 16
+    n_hit = 0
+    for l in rows:
+        x, foreseen = int(l[1]), int(l[2])
+        n_hit += foreseen
+        jb = J.make_jobs(W, H, [x], [48], 16, 16, method=J.STAR, subme=3, merange=20, qp=30,
+                         qmvp=(4, -(x // 16) if foreseen else 7), mvc=[[x // 8, 2]])
+        jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -20, -20, 20, 20
+        exp, _ = oracle.search(fr[0], [fr[1]], jb)
+        assert (int(l[3]), int(l[4]), int(l[5])) == (int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])), l
+    stats = [l for l in lines if l[0] == "fieldstats"][0]
+    assert [int(v) for v in stats[1:]] == [n_hit, len(rows) - n_hit, len(rows)]

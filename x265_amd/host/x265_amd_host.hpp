@@ -15,6 +15,9 @@
 #include <stdint.h>
 #include <stdexcept>
 #include <string>
+#include <string.h>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "../../include/x265_amd.h"
@@ -99,10 +102,98 @@ private:
     x265amd_ctx *m_ctx = nullptr;
 };
 
+// A motion field computed AHEAD of the CU analysis: the searches TEncSearch::predInterSearch is
+// expected to ask for (Lib/TLibEncoder/TEncSearch.cpp:2392-2451: one motionEstimate per PU, list and
+// reference, with a predictor the caller can often foresee, e.g. from the lookahead's half-resolution
+// MVs) are described once, run as ONE batch, and served from memory when the call site asks.  A
+// request is a hit only if every argument equals the planned one, so a hit returns exactly what the
+// call would have computed; anything else is a miss and is searched on the spot.
+class MotionField
+{
+public:
+    explicit MotionField(Context &ctx) : m_ctx(ctx) {}
+
+    // plan one search; `job` as MotionEstimate::makeJob builds it (ref_idx is assigned here)
+    int add(const ReferencePlanes &ref, x265amd_me_job job)
+    {
+        int slot = -1;
+        for (size_t i = 0; i < m_refs.size(); i++)
+            if (m_refs[i] == ref.plane_id)
+                slot = (int)i;
+        if (slot < 0)
+        {
+            if (m_refs.size() >= X265AMD_MAX_REFS)
+                throw std::runtime_error("x265_amd: too many reference planes in one motion field");
+            slot = (int)m_refs.size();
+            m_refs.push_back(ref.plane_id);
+        }
+        job.ref_idx = (uint8_t)slot;
+        m_index[key(ref.plane_id, job)] = (int)m_jobs.size();
+        m_jobs.push_back(job);
+        return (int)m_jobs.size() - 1;
+    }
+    // search everything planned against the current picture `enc`
+    void run(const ReferencePlanes &enc)
+    {
+        m_results.resize(m_jobs.size());
+        m_enc = enc.plane_id;
+        if (!m_jobs.empty())
+            m_ctx.check(x265amd_me_search_batch(m_ctx.get(), enc.plane_id, m_refs.data(), (int)m_refs.size(),
+                                                m_jobs.data(), (int)m_jobs.size(), m_results.data()));
+        m_valid = true;
+    }
+    // the stored result of a request identical to a planned one
+    bool lookup(const ReferencePlanes &enc, const ReferencePlanes &ref, x265amd_me_job want, x265amd_me_result &out)
+    {
+        if (m_valid && enc.plane_id == m_enc)
+        {
+            std::map<Key, int>::const_iterator it = m_index.find(key(ref.plane_id, want));
+            if (it != m_index.end())
+            {
+                want.ref_idx = m_jobs[it->second].ref_idx;
+                if (!memcmp(&want, &m_jobs[it->second], sizeof(want)))
+                {
+                    out = m_results[it->second];
+                    m_hits++;
+                    return true;
+                }
+            }
+        }
+        m_misses++;
+        return false;
+    }
+    void clear() { m_jobs.clear(); m_refs.clear(); m_index.clear(); m_results.clear(); m_valid = false; }
+    size_t size() const { return m_jobs.size(); }
+    unsigned hits() const { return m_hits; }
+    unsigned misses() const { return m_misses; }
+    const std::vector<x265amd_me_result> &results() const { return m_results; }
+
+private:
+    typedef std::tuple<int, int, int, int, int> Key;       // reference plane, PU x, y, w, h
+    static Key key(int ref, const x265amd_me_job &j) { return Key(ref, j.pu_x, j.pu_y, j.w, j.h); }
+
+    Context &m_ctx;
+    std::vector<x265amd_me_job> m_jobs;
+    std::vector<int> m_refs;
+    std::vector<x265amd_me_result> m_results;
+    std::map<Key, int> m_index;
+    int m_enc = -1;
+    bool m_valid = false;
+    unsigned m_hits = 0, m_misses = 0;
+};
+
 class MotionEstimate
 {
 public:
     explicit MotionEstimate(Context &ctx) : m_ctx(ctx) {}
+
+    // consult `field` (may be NULL) before searching: see MotionField
+    void attachField(MotionField *field) { m_field = field; }
+    // the job the next motionEstimate() with these arguments would run (for MotionField::add)
+    x265amd_me_job plan(const MV &mvmin, const MV &mvmax, const MV &qmvp, int numCandidates, const MV *mvc, int merange)
+    {
+        return makeJob(mvmin, mvmax, qmvp, numCandidates, mvc, merange);
+    }
 
     void setSearchMethod(int i) { m_method = i; }                 // motion.h:72
     void setSubpelRefine(int i) { m_subme = i; }                  // motion.h:74
@@ -130,7 +221,8 @@ public:
         x265amd_me_job j = makeJob(mvmin, mvmax, qmvp, numCandidates, mvc, merange);
         x265amd_me_result r;
         int refs[1] = { ref->plane_id };
-        m_ctx.check(x265amd_me_search_batch(m_ctx.get(), m_enc.plane_id, refs, 1, &j, 1, &r));
+        if (!m_field || !m_field->lookup(m_enc, *ref, j, r))
+            m_ctx.check(x265amd_me_search_batch(m_ctx.get(), m_enc.plane_id, refs, 1, &j, 1, &r));
         outQMv = MV(r.mvx, r.mvy);
         return r.cost;
     }
@@ -194,6 +286,7 @@ private:
     }
 
     Context &m_ctx;
+    MotionField *m_field = nullptr;
     ReferencePlanes m_enc = { -1, 0 };
     int m_method = 3, m_subme = 5;          // the reference's defaults (motion.cpp:82-85)
     unsigned m_qp = 32;
