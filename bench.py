@@ -142,6 +142,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if os.environ.get("X265AMD_BENCH_TRACE"):       # a stuck rank shows where it is
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("X265AMD_BENCH_TRACE_AFTER", "90")), exit=False)
     trace("process group up")
     from x265_amd.api import Engine
     eng = Engine(local_rank)
@@ -223,6 +226,18 @@ def main():
     # algorithmic HBM bytes of one launch: enc plane + ref plane read once, jobs read, results written
     alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
     achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
+
+    # ---- the exchange step alone (N > 1): reference plane from rank 0 to every rank ----------------
+    bcast_us = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            xd.broadcast_plane(ref_bufs[0], 0, engine=eng)
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e6], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bcast_us = float(t.item())
 
     if args.only_primary:
         if rank == 0:
@@ -326,7 +341,9 @@ def main():
                    # subme 5 = 1 + 8 + 8 SATD evaluations per PU (encoder/motion.cpp:57); the rest are SADs
                    "satd_evals_per_frame": 17 * int(len(hex_jobs)),
                    "sad_evals_per_frame": evals / (args.steps * world) - 17 * int(len(hex_jobs)),
-                   "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world},
+                   "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world,
+                   # the collective alone, host-bracketed (it is also inside every timed step)
+                   "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
         "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},

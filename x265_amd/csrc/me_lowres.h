@@ -78,10 +78,11 @@ __global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo
 // of the neighbour it needs with device-scope atomic loads until it differs.  No fences, hence no
 // cache write-backs or invalidations.  Row y waits only on row y + 1, i.e. workgroup b only on
 // workgroup b - 1 of the same pair, which was dispatched earlier: the chain always makes progress.
-// A bounded spin guards against a lost predecessor.
+// A bounded spin guards against a lost predecessor: the row that gives up stops waiting altogether,
+// finishes with whatever it reads, and the call reports the failure.
 struct LookPair { int32_t enc_plane, ref_plane; };
 
-constexpr int LOOK_SPIN_LIMIT = 1 << 24;
+constexpr int LOOK_SPIN_LIMIT = 1 << 20;      // about a second; a CU normally appears within tens of microseconds
 constexpr int LOOK_UNSET = 0x7fff7fff;
 
 struct LookLeaf
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const
         // (the PU is cached while the neighbours may still be busy)
         W.bind(lds, enc, ref, 8 * cux, 8 * cuy, 8 * cux, 8 * cuy, 8, 8, cost, flags, true);
         W.stamp(1);
-        if (have_b)
+        if (have_b && !failed)              // (after one lost neighbour the row only runs to its end)
         {
             const int v = LookLeaf::wait_mv3(below, (cux > 0 ? 1 : 0) | 2 | (have_r ? 4 : 0));
             w_bl = __builtin_amdgcn_readlane(v, 0);
