@@ -82,7 +82,9 @@ __global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo
 // finishes with whatever it reads, and the call reports the failure.
 struct LookPair { int32_t enc_plane, ref_plane; };
 
-constexpr int LOOK_SPIN_LIMIT = 1 << 20;      // about a second; a CU normally appears within tens of microseconds
+constexpr long long LOOK_WAIT_TICKS = 10ll * 100000000;   // 10 s of the 100 MHz real-time counter (a CU normally appears
+                                                          // within tens of microseconds; an exhaustive search over a whole
+                                                          // small frame can take tens of milliseconds per CU)
 constexpr int LOOK_UNSET = 0x7fff7fff;
 
 struct LookLeaf
@@ -90,18 +92,19 @@ struct LookLeaf
     // MV words (mvy << 16 | mvx & 0xffff) of the lower-left, lower and lower-right neighbours
     // (`below` - 1, `below`, `below` + 1; bit k of `mask`: neighbour k exists), once they are all
     // there: lanes 0..2 poll one each.  Returned per lane; LOOK_UNSET in a lane that gave up at the
-    // spin limit, 0 for an absent neighbour.  Out of line: the kernel body keeps only uniform
+    // time limit, 0 for an absent neighbour.  Out of line: the kernel body keeps only uniform
     // control flow.
     static __device__ __noinline__ int wait_mv3(const x265amd_me_result *below, int mask_)
     {
         const int mask = uni(mask_), lane = lane_id();
         const bool mine = lane < 3 && ((mask >> lane) & 1);
         int w = mine ? LOOK_UNSET : 0;
-        for (int spin = 0; spin < LOOK_SPIN_LIMIT; spin++)
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        for (;;)
         {
             if (mine)
                 w = __hip_atomic_load((const int*)(below + (lane - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(w == LOOK_UNSET) == 0)
+            if (__ballot(w == LOOK_UNSET) == 0 || (long long)__builtin_amdgcn_s_memrealtime() - t0 > LOOK_WAIT_TICKS)
                 break;
             __builtin_amdgcn_s_sleep(2);
         }
