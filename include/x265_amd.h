@@ -42,7 +42,16 @@ enum
 enum { X265AMD_SAD = 0, X265AMD_SATD = 1, X265AMD_SA8D = 2 };
 
 /* search methods: X265_DIA_SEARCH .. X265_FULL_SEARCH (x265.h, --me 0..4) */
-enum { X265AMD_DIA = 0, X265AMD_HEX = 1, X265AMD_UMH = 2, X265AMD_STAR = 3, X265AMD_FULL = 4 };
+enum { X265AMD_DIA = 0, X265AMD_HEX = 1, X265AMD_UMH = 2, X265AMD_STAR = 3, X265AMD_FULL = 4,
+       /* Not a MotionEstimate method: the search of TEncSearch::xMotionEstimation, the bidirectional
+        * refinement (Lib/TLibEncoder/TEncSearch.cpp:2960-3005).  The job's encoder plane holds the
+        * caller's modified block (2*org - otherPred, TComYuv::removeHighFreq) at the PU position;
+        * [mvmin, mvmax] is xSetSearchRange's result around the uni-directional MV (:2983), qmvp the
+        * predictor of m_me.setMVP (:2991).  Runs xPatternSearch (exhaustive SAD + mvcost, :3026-3085)
+        * and xPatternRefinement at half-pel and quarter-pel (9-point SATD + mvcost, :224-285);
+        * result = (outmv in q-pel, the quarter-pel refinement's cost, :3000).  merange, subme, numc,
+        * mvc are ignored; the range must not be empty. */
+       X265AMD_BIPRED = 5 };
 
 typedef struct x265amd_ctx x265amd_ctx;
 
@@ -129,7 +138,7 @@ typedef struct x265amd_me_job
     int16_t mvmax_x, mvmax_y;
     int16_t qmvp_x, qmvp_y;             /* q-pel predictor (const MV& qmvp) */
     int16_t merange;
-    uint8_t method;                     /* X265AMD_DIA .. X265AMD_FULL */
+    uint8_t method;                     /* X265AMD_DIA .. X265AMD_FULL, or X265AMD_BIPRED */
     uint8_t subme;                      /* 0..7, workload[] of encoder/motion.cpp:51-60 */
     uint8_t qp;                         /* 0..51 */
     uint8_t numc;                       /* numCandidates, <= X265AMD_MAX_MVC */

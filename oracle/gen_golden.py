@@ -50,6 +50,12 @@ def main():
             out["res_" + kind] = ref.search(fr[0], [fr[1], fr[2]], jobs)
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "search_u%d.npz" % bits), **out)
         print("bits", bits, "search jobs", len(jobs))
+        # bidirectional refinement: reference primitives / filters / MV cost under the control flow of
+        # xPatternSearch + xPatternRefinement (oracle/ref_shim.cpp: ref_bipred_search)
+        bj = G.bipred_jobs(bits)
+        mod, rf = G.bipred_frames(bits)
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "bipred_u%d.npz" % bits), res=ref.search(mod, [rf], bj),
+                            jobs_crc=np.array([zlib.crc32(bj.tobytes())], dtype=np.uint32))
         # lookahead path: half-resolution planes, isLowres searches, neighbour-predicted MV fields
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "lowres_u%d.npz" % bits), **G.run_lowres_suite(ref, bits))
     ref = Reference(8)

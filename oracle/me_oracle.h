@@ -29,7 +29,10 @@ extern "C" {
 /* cost kinds */
 enum { MEO_SAD = 0, MEO_SATD = 1, MEO_SA8D_INTER = 2, MEO_SA8D_SQUARE = 3 };
 /* search methods, numbering of x265.h (X265_DIA_SEARCH ... X265_FULL_SEARCH) */
-enum { MEO_DIA = 0, MEO_HEX = 1, MEO_UMH = 2, MEO_STAR = 3, MEO_FULL = 4 };
+enum { MEO_DIA = 0, MEO_HEX = 1, MEO_UMH = 2, MEO_STAR = 3, MEO_FULL = 4,
+       /* not a MotionEstimate method: the search of TEncSearch::xMotionEstimation (bidirectional
+        * refinement: exhaustive SAD scan + two 9-point SATD refinements, TEncSearch.cpp:2993-3000) */
+       MEO_BIPRED = 5 };
 
 /* One motionEstimate() call, fully described (reference call sequence:
  * setQP; setSearchMethod; setSubpelRefine; setSourcePlane; setSourcePU; motionEstimate). */
@@ -41,7 +44,7 @@ typedef struct meo_job
     int16_t mvmax_x, mvmax_y;
     int16_t qmvp_x, qmvp_y;      /* q-pel predictor */
     int16_t merange;
-    uint8_t method;              /* 0 DIA, 1 HEX, 2 UMH, 3 STAR, 4 FULL */
+    uint8_t method;              /* 0 DIA, 1 HEX, 2 UMH, 3 STAR, 4 FULL, 5 BIPRED */
     uint8_t subme;               /* 0..7 */
     uint8_t qp;                  /* 0..51 */
     uint8_t numc;                /* number of candidates, <= MEO_MAX_MVC */

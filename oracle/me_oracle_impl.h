@@ -450,8 +450,63 @@ static const int8_t SUF(k_star_offsets)[16][2] =   /* two-point refinement table
 };
 
 /* the whole of MotionEstimate::motionEstimate (motion.cpp:277-866) */
+/* The search of TEncSearch::xMotionEstimation (bidirectional refinement,
+ * Lib/TLibEncoder/TEncSearch.cpp:2993-3000): xPatternSearch (:3026-3085), an exhaustive raster
+ * scan of [mvmin, mvmax] with SAD + mvcost and strict `<`, then xPatternRefinement (:224-285) at
+ * half-pel and at quarter-pel: 9 candidates each, SATD of the interpolated block + mvcost, in the
+ * order of s_mvRefineHpel / s_mvRefineQPel (:59-83).  The cached PU is whatever the encoder plane
+ * holds at the PU position (the caller's 2*org - otherPred block).  Returns the quarter-pel
+ * refinement's cost (what xMotionEstimation keeps in outCost before its bit accounting). */
+static int SUF(bipred_search)(SUF(state) *st, const meo_job *j, int16_t *outx, int16_t *outy)
+{
+    static const int8_t refine_hpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+    static const int8_t refine_qpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
+    st->ikind = MEO_SAD;
+    st->mvpx = j->qmvp_x;
+    st->mvpy = j->qmvp_y;
+    unsigned bcost = ~0u;
+    int16_t bx = 0, by = 0;
+    for (int y = j->mvmin_y; y <= j->mvmax_y; y++)
+        for (int x = j->mvmin_x; x <= j->mvmax_x; x++)
+        {
+            unsigned c = (unsigned)SUF(cost_at)(st, x, y);
+            if (c < bcost)
+            {
+                bcost = c;
+                bx = (int16_t)x;
+                by = (int16_t)y;
+            }
+        }
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const int8_t (*tab)[2] = pass ? refine_qpel : refine_hpel;
+        const int scale = pass ? 1 : 2;
+        bx = (int16_t)(bx << 1);            /* full-pel -> half-pel -> quarter-pel units */
+        by = (int16_t)(by << 1);
+        int best = 0;
+        bcost = ~0u;
+        for (int i = 0; i < 9; i++)
+        {
+            int16_t qx = (int16_t)((int16_t)(bx + tab[i][0]) * scale), qy = (int16_t)((int16_t)(by + tab[i][1]) * scale);
+            unsigned c = (unsigned)SUF(mvcost)(st, qx, qy) + (unsigned)SUF(subpel_cmp)(st, qx, qy, MEO_SATD);
+            if (c < bcost)
+            {
+                bcost = c;
+                best = i;
+            }
+        }
+        bx = (int16_t)(bx + tab[best][0]);
+        by = (int16_t)(by + tab[best][1]);
+    }
+    *outx = bx;
+    *outy = by;
+    return (int)bcost;
+}
+
 static int SUF(search)(SUF(state) *st, const meo_job *j, int16_t *outx, int16_t *outy)
 {
+    if (j->method == MEO_BIPRED)
+        return SUF(bipred_search)(st, j, outx, outy);
     static const int8_t hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
     static const int8_t square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
     static const int8_t hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },

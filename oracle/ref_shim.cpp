@@ -276,6 +276,94 @@ void ref_lookahead_me(void *h, pixel **enc_planes, pixel **ref_planes, intptr_t 
     delete[] mvs;
 }
 
+/* Driver for the search of TEncSearch::xMotionEstimation (bidirectional refinement): the control flow
+ * of xPatternSearch and xPatternRefinement (Lib/TLibEncoder/TEncSearch.cpp:224-285, 2993-3000,
+ * 3026-3085; TEncSearch.cpp itself needs the whole encoder to link) around the reference's own
+ * primitives, interpolation filters and MV cost.  enc holds the caller's modified block at the PU
+ * position.  Returns the quarter-pel refinement's cost; out_mv = q-pel MV. */
+unsigned ref_bipred_search(void *h, pixel *enc, intptr_t encStride, pixel *ref, intptr_t stride, int puOffset,
+                           int width, int height, const int16_t *mvmin, const int16_t *mvmax, const int16_t *mvp,
+                           int qp, int16_t *out_mv)
+{
+    static const MV refineHpel[9] = { MV(0, 0), MV(0, -1), MV(0, 1), MV(-1, 0), MV(1, 0), MV(-1, -1), MV(1, -1), MV(-1, 1), MV(1, 1) };
+    static const MV refineQPel[9] = { MV(0, 0), MV(0, -1), MV(0, 1), MV(-1, -1), MV(1, -1), MV(-1, 0), MV(1, 0), MV(-1, 1), MV(1, 1) };
+    RefME *r = (RefME*)h;
+    r->me.setQP(qp);
+    r->me.setSourcePlane(enc, encStride);
+    r->me.setSourcePU(puOffset, width, height);
+    r->me.setMVP(MV(mvp[0], mvp[1]));
+    pixel *fenc = r->me.fenc;
+    pixel *fref = ref + puOffset;
+    int part = PartitionFromSizes(width, height);
+    pixelcmp_t sad = primitives.sad[part];
+    pixelcmp_x4_t sad_x4 = primitives.sad_x4[part];
+    pixelcmp_t satd = primitives.satd[part];
+    ALIGN_VAR_32(int, costs[16]);
+    MV outmv(0, 0);
+    unsigned bcost = ~0u;
+    for (int y = mvmin[1]; y <= mvmax[1]; y++)
+    {
+        pixel *row = fref + y * stride;
+        for (int x = mvmin[0]; x <= mvmax[0]; x++)
+        {
+            MV mv(x, y);
+            if (x + 3 <= mvmax[0])
+            {
+                sad_x4(fenc, row + x, row + x + 1, row + x + 2, row + x + 3, stride, costs);
+                for (int k = 0; k < 4; k++, mv.x++)
+                {
+                    unsigned c = costs[k] + r->me.mvcost(mv << 2);
+                    if (c < bcost) { bcost = c; outmv = mv; }
+                }
+                x += 3;
+            }
+            else
+            {
+                unsigned c = sad(fenc, FENC_STRIDE, row + x, stride) + r->me.mvcost(mv << 2);
+                if (c < bcost) { bcost = c; outmv = mv; }
+            }
+        }
+    }
+    ALIGN_VAR_32(pixel, qref[64 * 64]);
+    short *tmp = new short[width * (height + 7)];
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const MV *tab = pass ? refineQPel : refineHpel;
+        const int fracBits = pass ? 1 : 2;
+        outmv <<= 1;
+        unsigned best = 0;
+        bcost = ~0u;
+        for (int i = 0; i < 9; i++)
+        {
+            MV mv = (outmv + tab[i]) * (int16_t)fracBits;
+            pixel *src = fref + (mv.x >> 2) + (mv.y >> 2) * stride;
+            int xFrac = mv.x & 3, yFrac = mv.y & 3;
+            unsigned cost = r->me.mvcost(mv);
+            if (!yFrac && !xFrac)
+                cost += satd(fenc, FENC_STRIDE, src, stride);
+            else
+            {
+                if (!yFrac)
+                    primitives.ipfilter_pp[FILTER_H_P_P_8](src, stride, qref, 64, width, height, g_lumaFilter[xFrac]);
+                else if (!xFrac)
+                    primitives.ipfilter_pp[FILTER_V_P_P_8](src, stride, qref, 64, width, height, g_lumaFilter[yFrac]);
+                else
+                {
+                    primitives.ipfilter_ps[FILTER_H_P_S_8](src - 3 * stride, stride, tmp, width, width, height + 7, g_lumaFilter[xFrac]);
+                    primitives.ipfilter_sp[FILTER_V_S_P_8](tmp + 3 * width, width, qref, 64, width, height, g_lumaFilter[yFrac]);
+                }
+                cost += satd(fenc, FENC_STRIDE, qref, 64);
+            }
+            if (cost < bcost) { bcost = cost; best = i; }
+        }
+        outmv += tab[best];
+    }
+    delete[] tmp;
+    out_mv[0] = outmv.x;
+    out_mv[1] = outmv.y;
+    return bcost;
+}
+
 /* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */
 int ref_me_buf(void *h, int kind, pixel *enc, intptr_t encStride, int puOffset, int w, int hgt,
                pixel *fref, intptr_t stride)

@@ -79,6 +79,13 @@ int main(int argc, char **argv)
         prim.sad_x4[27](e0, r0, r0 + 1, r0 + 2, r0 + 3, stride, res);   // PARTITION_16x16 == 27; fenc stride is 64 by contract
         printf("prim %d %d %d %d %d\n", prim.sad[27](e0, stride, r0 + 5, stride), prim.satd[27](e0, stride, r0 + 5, stride),
                prim.sa8d_inter[27](e0, stride, r0 + 5, stride), res[0], res[3]);
+        // (4b) bidirectional refinement: +-4 around (3,-2), predictor (9,-7), PU (96,64) 32x16
+        {
+            me.setSourcePUxy(96, 64, 32, 16);
+            x265amd::MV out;
+            int cost = me.bipredSearch(&pr, x265amd::MV(-1, -6), x265amd::MV(7, 2), x265amd::MV(9, -7), out);
+            printf("bipred %d %d %d\n", out.x, out.y, cost);
+        }
         // (5) lookahead: half-resolution sets of both pictures, one whole-frame search, a few CUs printed
         if (M >= 16)
         {

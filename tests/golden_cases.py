@@ -113,6 +113,35 @@ def field_jobs() -> np.ndarray:
     return J.frame_jobs(FIELD_W, FIELD_H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=32)
 
 
+# bidirectional refinement (TEncSearch::xMotionEstimation)
+def bipred_frames(bits: int):
+    """(modified source plane = clip(2 * org - other prediction), reference plane)"""
+    depth = 8 if bits == 8 else 10
+    fr = synth.make_sequence(SEARCH_W, SEARCH_H, 3, seed=91 + bits, bit_depth=depth, kind="motion")
+    mod = np.clip(2 * fr[0].astype(np.int32) - fr[2].astype(np.int32), 0, (1 << depth) - 1).astype(fr[0].dtype)
+    return mod, fr[1]
+
+
+def bipred_jobs(bits: int) -> np.ndarray:
+    """searches of +-bipredSearchRange (4, also 2 and 7) around an initial MV, every PU shape"""
+    rng = np.random.default_rng(7000 + bits)
+    W, H = SEARCH_W, SEARCH_H
+    out = []
+    for (w, h) in SEARCH_SHAPES:
+        for rep in range(6):
+            px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            j = J.make_jobs(W, H, [px], [py], w, h, method=J.BIPRED, subme=0, merange=4, qp=int(rng.choice([22, 32, 40])),
+                            qmvp=(int(rng.integers(-80, 80)), int(rng.integers(-80, 80))))
+            cx, cy = int(rng.integers(-20, 20)), int(rng.integers(-20, 20))       # the uni-directional MV, full-pel
+            r = int(rng.choice([4, 4, 2, 7]))
+            j["mvmin_x"], j["mvmax_x"], j["mvmin_y"], j["mvmax_y"] = cx - r, cx + r, cy - r, cy + r
+            if rep == 5:
+                j["mvmax_x"] = cx - r + int(rng.integers(0, 3))                  # narrow ranges: the single-SAD tail
+            out.append(j)
+    return np.concatenate(out)
+
+
 # lookahead (half-resolution) path
 LOWRES_W, LOWRES_H = 364, 214          # halves to 182 x 107: neither a multiple of 8, stride rounds up to 32
 LOOKAHEAD_CONFIGS = ((1, 1, 16, 12), (0, 2, 16, 12), (3, 3, 8, 22), (2, 5, 16, 12), (4, 1, 4, 30))  # method, subme, merange, qp

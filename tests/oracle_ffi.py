@@ -168,6 +168,9 @@ class Reference:
         L.ref_me_buf.restype = C.c_int
         L.ref_me_buf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
         L.ref_lowres_core.argtypes = [C.c_void_p] * 5 + [C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int]
+        L.ref_bipred_search.restype = C.c_uint
+        L.ref_bipred_search.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_lookahead_me.restype = None
         L.ref_lookahead_me.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_ssize_t] + \
                                       [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
@@ -256,6 +259,13 @@ class Reference:
             qmvp = np.array([j["qmvp_x"], j["qmvp_y"]], dtype=np.int16)
             mvc = np.ascontiguousarray(j["mvc"], dtype=np.int16)
             omv = np.zeros(2, dtype=np.int16)
+            if int(j["method"]) == 5:       # the bidirectional-refinement search (no MotionEstimate method)
+                cost = self.lib.ref_bipred_search(self.me, enc0, es, plane_origin(ref, margin), ref.shape[1],
+                                                  int(j["pu_y"]) * es + int(j["pu_x"]), int(j["w"]), int(j["h"]),
+                                                  mvmin.ctypes.data, mvmax.ctypes.data, qmvp.ctypes.data, int(j["qp"]),
+                                                  omv.ctypes.data)
+                out[i] = (omv[0], omv[1], cost)
+                continue
             cost = self.lib.ref_me_search(self.me, enc0, es, plane_origin(ref, margin), ref.shape[1], lr,
                                           int(j["pu_y"]) * es + int(j["pu_x"]), int(j["w"]), int(j["h"]),
                                           mvmin.ctypes.data, mvmax.ctypes.data, qmvp.ctypes.data,

@@ -84,3 +84,9 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
         assert (int(l[3]), int(l[4]), int(l[5])) == (int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])), l
     stats = [l for l in lines if l[0] == "fieldstats"][0]
     assert [int(v) for v in stats[1:]] == [n_hit, len(rows) - n_hit, len(rows)]
+    # (4b) bidirectional refinement through the mirror
+    jb = J.make_jobs(W, H, [96], [64], 32, 16, method=J.BIPRED, subme=0, merange=0, qp=30, qmvp=(9, -7))
+    jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -1, -6, 7, 2
+    exp, _ = oracle.search(fr[0], [fr[1]], jb)
+    bp = [l for l in lines if l[0] == "bipred"][0]
+    assert [int(v) for v in bp[1:]] == [int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])]

@@ -303,3 +303,32 @@ def test_search_window_outside_margins_is_rejected(eng):
         eng.search(ids[0], [ids[1]], bad)
     for i in ids:
         eng.release_plane(i)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_bidirectional_refinement_matches_reference_vectors(eng, oracle, bits):
+    """X265AMD_BIPRED jobs (exhaustive SAD scan + two 9-point SATD refinements on a modified source
+    block) against the vectors produced with the reference's primitives, through the host batch call
+    and through a planned job list (exhaustive kernel + general kernel)"""
+    import os
+    import golden_cases as G
+    gold = np.load(os.path.join(G.GOLDEN_DIR, "bipred_u%d.npz" % bits), allow_pickle=False)["res"]
+    depth = 8 if bits == 8 else 10
+    mod, rf = G.bipred_frames(bits)
+    jobs = G.bipred_jobs(bits)
+    ids = [eng.upload_plane(mod, bit_depth=depth), eng.upload_plane(rf, bit_depth=depth)]
+    got = eng.search(ids[0], [ids[1]], jobs)
+    bad = np.nonzero(got != gold)[0]
+    assert bad.size == 0, (jobs[bad[:3]], got[bad[:3]], gold[bad[:3]])
+    jl = eng.make_joblist(jobs, bytes_per_px=bits // 8)
+    got2 = jl.run(ids[0], [ids[1]])
+    jl.close()
+    assert np.array_equal(got2, gold)
+    # mixed with ordinary searches in one batch
+    mixed = np.concatenate([jobs[:20], J.make_jobs(G.SEARCH_W, G.SEARCH_H, [64, 128], [32, 64], 16, 16, method=J.HEX, subme=3,
+                                                   merange=16, qp=30)])
+    got3 = eng.search(ids[0], [ids[1]], mixed)
+    exp3, _ = oracle.search(mod, [rf], mixed, bit_depth=depth)
+    assert np.array_equal(got3, exp3)
+    for i in ids:
+        eng.release_plane(i)

@@ -85,3 +85,14 @@ def test_lookahead_path_matches_reference_vectors(oracle, bits):
     assert set(gold.files) == set(got.keys())
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.nonzero(gold[k] != got[k])[0][:5])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_bidirectional_refinement_matches_reference_vectors(oracle, bits):
+    gold = _load("bipred_u%d.npz" % bits)
+    jobs = G.bipred_jobs(bits)
+    assert zlib.crc32(jobs.tobytes()) == int(gold["jobs_crc"][0])
+    mod, rf = G.bipred_frames(bits)
+    got, _ = oracle.search(mod, [rf], jobs, bit_depth=8 if bits == 8 else 10)
+    bad = np.nonzero(got != gold["res"])[0]
+    assert bad.size == 0, (jobs[bad[:3]], got[bad[:3]], gold["res"][bad[:3]])

@@ -23,7 +23,7 @@ template <class J>
 __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
 {
     int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-    return j.method == X265AMD_FULL && j.icost == X265AMD_SAD && (bpp == 1 || bpp == 2) &&
+    return (j.method == X265AMD_FULL || j.method == X265AMD_BIPRED) && j.icost == X265AMD_SAD && (bpp == 1 || bpp == 2) &&
            nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
 }
 

@@ -30,6 +30,9 @@ __constant__ int c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1
 // workload[] (motion.cpp:51-60): hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd
 __constant__ int c_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
                                          { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+// s_mvRefineHpel / s_mvRefineQPel (Lib/TLibEncoder/TEncSearch.cpp:59-83): the two 9-point orders differ
+__constant__ int c_refine_hpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+__constant__ int c_refine_qpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
 __constant__ int c_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
 
 #define XA_S16(v) ((int)(int16_t)(v))
@@ -417,6 +420,99 @@ struct Search
         return bprecost;
     }
 
+    // Exhaustive raster scan of [mvmin, mvmax] with strict `<` (motion.cpp:738-771 and
+    // TEncSearch::xPatternSearch, TEncSearch.cpp:3026-3085), improving on the current bcost / bmv.
+    __device__ __forceinline__ void raster_scan(const FullBest *fb, int fb_stride)
+    {
+        if (fb)
+        {
+            // the exhaustive raster scan ran in its own kernel; its winner is the first
+            // minimum in raster order, which is what strict-`<` updates would have kept
+            // combine the slabs: lowest cost, then lowest raster index
+            const int nxr = j.mvmax_x - j.mvmin_x + 1;
+            int fcost = 0x7fffffff, fidx = 0x7fffffff, fx = 0, fy = 0;
+            for (int s = 0; s < fb_stride; s++)
+            {
+                int c = uni(fb[s].cost), x = uni(fb[s].mvx), y = uni(fb[s].mvy);   // (vector loads: pin to scalar registers)
+                int idx = (y - j.mvmin_y) * nxr + (x - j.mvmin_x);
+                if (c < fcost || (c == fcost && c != 0x7fffffff && idx < fidx))
+                {
+                    fcost = c; fidx = idx; fx = x; fy = y;
+                }
+            }
+            if (fcost < bcost)
+            {
+                bcost = fcost;
+                bmx = fx;
+                bmy = fy;
+            }
+            int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+            W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;
+        }
+        else
+        {
+            for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty++)
+            {
+                int tx = j.mvmin_x;
+                for (; tx + 3 <= j.mvmax_x; tx += 4)
+                {
+                    int x[4] = { tx, tx + 1, tx + 2, tx + 3 }, y[4] = { ty, ty, ty, ty };
+                    try_points<4>(x, y, x, y);
+                }
+                for (; tx <= j.mvmax_x; tx++)
+                    try_mv(tx, ty);
+            }
+        }
+    }
+
+    // The search of TEncSearch::xMotionEstimation (bidirectional refinement, TEncSearch.cpp:2993-3000):
+    // xPatternSearch, then xPatternRefinement (TEncSearch.cpp:224-285) at half-pel and at quarter-pel -
+    // 9 candidates each, SATD of the interpolated block + mvcost, first minimum in table order.
+    __device__ __forceinline__ int run_bipred(const FullBest *fb, int fb_stride, int &outx, int &outy)
+    {
+        W.ikind = X265AMD_SAD;
+        bcost = 0x7fffffff;
+        bmx = bmy = 0;
+        raster_scan(fb, fb_stride);
+        int ux = bmx, uy = bmy;             // full-pel, then half-pel, then quarter-pel units
+#pragma nounroll
+        for (int pass = 0; pass < 2; pass++)
+        {
+            ux = XA_S16(ux << 1);
+            uy = XA_S16(uy << 1);
+            const int (*tab)[2] = pass ? c_refine_qpel : c_refine_hpel;
+            const int scale = pass ? 1 : 2;
+            int qx[8], qy[8], c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                qx[i] = XA_S16(XA_S16(ux + tab[i][0]) * scale);
+                qy[i] = XA_S16(XA_S16(uy + tab[i][1]) * scale);
+            }
+            W.subpel_cost8(8, qx, qy, X265AMD_SATD, c);
+            const int c8 = W.subpel_cost(XA_S16(XA_S16(ux + tab[8][0]) * scale), XA_S16(XA_S16(uy + tab[8][1]) * scale), X265AMD_SATD, true);
+            int best = 0;
+            bcost = c[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++)
+                if (c[i] < bcost)
+                {
+                    bcost = c[i];
+                    best = i;
+                }
+            if (c8 < bcost)
+            {
+                bcost = c8;
+                best = 8;
+            }
+            ux = XA_S16(ux + tab[best][0]);
+            uy = XA_S16(uy + tab[best][1]);
+        }
+        outx = ux;
+        outy = uy;
+        return bcost;
+    }
+
     // ---------------------------------------------------------------- the search
     __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
     {
@@ -424,6 +520,8 @@ struct Search
         W.ikind = j.icost;
         W.set_mvp(j.qmvp_x, j.qmvp_y);      // setMVP (bitcost.h:43)
         W.stamp(2);
+        if (j.method == X265AMD_BIPRED)
+            return run_bipred(fb, fb_stride, outx, outy);
         const int qminx = XA_S16(j.mvmin_x << 2), qminy = XA_S16(j.mvmin_y << 2);
         const int qmaxx = XA_S16(j.mvmax_x << 2), qmaxy = XA_S16(j.mvmax_y << 2);
         auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };   // MV::clipped, mv.h:88-93
@@ -679,45 +777,7 @@ struct Search
 
         case X265AMD_FULL:  // motion.cpp:738-771
         default:
-            if (fb)
-            {
-                // the exhaustive raster scan ran in its own kernel; its winner is the first
-                // minimum in raster order, which is what strict-`<` updates would have kept
-                // combine the slabs: lowest cost, then lowest raster index
-                const int nxr = j.mvmax_x - j.mvmin_x + 1;
-                int fcost = 0x7fffffff, fidx = 0x7fffffff, fx = 0, fy = 0;
-                for (int s = 0; s < fb_stride; s++)
-                {
-                    int c = uni(fb[s].cost), x = uni(fb[s].mvx), y = uni(fb[s].mvy);   // (vector loads: pin to scalar registers)
-                    int idx = (y - j.mvmin_y) * nxr + (x - j.mvmin_x);
-                    if (c < fcost || (c == fcost && c != 0x7fffffff && idx < fidx))
-                    {
-                        fcost = c; fidx = idx; fx = x; fy = y;
-                    }
-                }
-                if (fcost < bcost)
-                {
-                    bcost = fcost;
-                    bmx = fx;
-                    bmy = fy;
-                }
-                int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-                W.evals += (nx > 0 && ny > 0) ? (unsigned)(nx * ny) : 0u;
-            }
-            else
-            {
-                for (int ty = j.mvmin_y; ty <= j.mvmax_y; ty++)
-                {
-                    int tx = j.mvmin_x;
-                    for (; tx + 3 <= j.mvmax_x; tx += 4)
-                    {
-                        int x[4] = { tx, tx + 1, tx + 2, tx + 3 }, y[4] = { ty, ty, ty, ty };
-                        try_points<4>(x, y, x, y);
-                    }
-                    for (; tx <= j.mvmax_x; tx++)
-                        try_mv(tx, ty);
-                }
-            }
+            raster_scan(fb, fb_stride);
             break;
         }
 

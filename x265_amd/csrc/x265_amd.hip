@@ -1111,12 +1111,14 @@ static int validate_jobs(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int 
         const x265amd_me_job &j = jobs[i];
         if (!valid_dim(j.w) || !valid_dim(j.h))
             return fail(c, X265AMD_ERR_INVALID, "job size is not a partition size");
-        if (j.method > X265AMD_FULL || j.subme > 7 || j.qp > 51 || j.numc > X265AMD_MAX_MVC ||
+        if (j.method > X265AMD_BIPRED || j.subme > 7 || j.qp > 51 || j.numc > X265AMD_MAX_MVC ||
             j.ref_idx >= n_refs || j.icost > X265AMD_SA8D || j.merange < 0)
             return fail(c, X265AMD_ERR_INVALID, "job field out of range");
         if (j.method == X265AMD_UMH && j.w == 4 && j.h == 4)
             return fail(c, X265AMD_ERR_INVALID, "UMH does not support 4x4 (the reference asserts, encoder/motion.cpp:447)");
-        if (j.method == X265AMD_FULL)
+        if (j.method == X265AMD_BIPRED && (j.icost != X265AMD_SAD || j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y))
+            return fail(c, X265AMD_ERR_INVALID, "a bidirectional-refinement job needs a non-empty range and the SAD metric");
+        if (j.method == X265AMD_FULL || j.method == X265AMD_BIPRED)
             *any_full = true;
     }
     return 0;

@@ -227,6 +227,22 @@ public:
         return r.cost;
     }
 
+    // The search of TEncSearch::xMotionEstimation (bidirectional refinement, TEncSearch.cpp:2993-3000):
+    // xPatternSearch over [mvmin, mvmax] + xPatternRefinement at half- and quarter-pel.  The source
+    // plane set by setSourcePlane must hold the modified block (2*org - otherPred) at the PU position.
+    // Returns the quarter-pel refinement's cost (outCost of TEncSearch.cpp:3000); outQMv in q-pel.
+    int bipredSearch(const ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &mvp, MV &outQMv)
+    {
+        x265amd_me_job j = makeJob(mvmin, mvmax, mvp, 0, NULL, 0);
+        j.method = X265AMD_BIPRED;
+        j.subme = 0;
+        x265amd_me_result r;
+        int refs[1] = { ref->plane_id };
+        m_ctx.check(x265amd_me_search_batch(m_ctx.get(), m_enc.plane_id, refs, 1, &j, 1, &r));
+        outQMv = MV(r.mvx, r.mvy);
+        return r.cost;
+    }
+
     // batched form: same arguments, result delivered by flush(); returns the job's index
     int queue(const ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp,
               int numCandidates, const MV *mvc, int merange)

@@ -12,6 +12,7 @@ import numpy as np
 MAX_MVC = 4
 
 DIA, HEX, UMH, STAR, FULL = 0, 1, 2, 3, 4
+BIPRED = 5      # the search of TEncSearch::xMotionEstimation (exhaustive SAD scan + two 9-point SATD refinements)
 SAD, SATD, SA8D = 0, 1, 2
 
 JOB_DTYPE = np.dtype([
