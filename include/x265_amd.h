@@ -84,6 +84,20 @@ int x265amd_plane_upload(x265amd_ctx *ctx, const void *host_base, int width, int
 int x265amd_plane_wrap_device(x265amd_ctx *ctx, void *dev_base, int width, int height,
                               int margin_x, int margin_y, intptr_t stride, int bytes_per_px, int bit_depth,
                               int *plane_id);
+/* Reference planes that become valid row by row.  The encoder publishes a reconstructed picture
+ * one CTU row at a time (FrameFilter: deblock/SAO the row, extend its borders, m_reconRowCount++,
+ * encoder/framefilter.cpp:201-262) and other frames may search the rows already published
+ * (refLagRows, encoder/frameencoder.cpp:893-918).  x265amd_plane_create makes an empty device plane of
+ * the TComPicYuv geometry; x265amd_plane_update_rows copies picture rows [y0, y0 + n_rows) -- the
+ * width interior pixels of each, from a host picture whose pixel (0,0) is `host_origin` -- and extends
+ * their borders on the device (left / right margins; the top margin with row 0, the bottom margin with
+ * the last row), so the margins need not be valid (or exist) on the host.  Searches queued afterwards
+ * see the rows; keeping a job's window inside the published rows is the caller's business, as it is in
+ * the reference (TEncSearch::xSetSearchRange's m_refLagPixels clamp, TEncSearch.cpp:3021-3023). */
+int x265amd_plane_create(x265amd_ctx *ctx, int width, int height, int margin_x, int margin_y, intptr_t stride,
+                         int bytes_per_px, int bit_depth, int *plane_id);
+int x265amd_plane_update_rows(x265amd_ctx *ctx, int plane_id, const void *host_origin, intptr_t host_stride,
+                              int y0, int n_rows);
 /* device address of the padded allocation of a plane (upload target / broadcast buffer) */
 void *x265amd_plane_device_ptr(x265amd_ctx *ctx, int plane_id);
 int x265amd_plane_release(x265amd_ctx *ctx, int plane_id);

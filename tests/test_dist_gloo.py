@@ -48,6 +48,14 @@ def _worker(rank, world, port, q):
         ring.prefetch(k + 1)
         assert np.array_equal(bufs[b].numpy(), frames[k]), k       # the buffer in use is untouched
         ring.release(k)
+    # row-wise publishing: the owner hands out the padded plane 48 rows at a time
+    rows = torch.from_numpy(frames[2].copy()) if rank == 0 else torch.zeros(frames[2].shape, dtype=torch.uint8)
+    for r0 in range(0, rows.shape[0], 48):
+        n = min(48, rows.shape[0] - r0)
+        xd.broadcast_plane_rows(rows, r0, n, src=0)
+        assert np.array_equal(rows.numpy()[:r0 + n], frames[2][:r0 + n])
+        if rank != 0 and r0 + n < rows.shape[0]:
+            assert not rows.numpy()[r0 + n:].any()              # rows not yet published stay untouched
     mine = xd.shard_frames(NFRAMES, rank, world)
     o = Oracle()
     local = [o.search(frames[f + 1], [ref.numpy()], jobs)[0] for f in mine]

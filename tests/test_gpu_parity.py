@@ -332,3 +332,36 @@ def test_bidirectional_refinement_matches_reference_vectors(eng, oracle, bits):
     assert np.array_equal(got3, exp3)
     for i in ids:
         eng.release_plane(i)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_rowwise_published_plane_equals_whole_upload(eng, oracle, bits):
+    """a reference plane filled CTU row by CTU row from an unpadded picture, borders extended on the
+    device, equals the plane uploaded whole with host-made borders - bytes and search results"""
+    depth = 8 if bits == 8 else 10
+    W, H = 208, 152                                   # the last CTU row is partial
+    fr = synth.make_sequence(W, H, 2, seed=66, bit_depth=depth)
+    M = synth.MARGIN
+    pic = np.ascontiguousarray(fr[1][M:M + H, M:M + W])
+    whole = eng.upload_plane(fr[1], bit_depth=depth)
+    rows = eng.create_plane(W, H, bytes_per_px=bits // 8, bit_depth=depth)
+    jobs = J.frame_jobs(W, H, sizes=(16,), method=J.HEX, subme=2, merange=16, qp=30)
+    enc = eng.upload_plane(fr[0], bit_depth=depth)
+    for y0 in range(0, H, 64):
+        n = min(64, H - y0)
+        eng.update_plane_rows(rows, pic, y0, n)
+        if y0 + n < H:
+            # rows published so far: searches whose windows stay above the published edge already work
+            jb = jobs[jobs["pu_y"] + 16 + 16 + 7 <= y0 + n].copy()
+            jb["mvmax_y"] = np.minimum(jb["mvmax_y"], y0 + n - 7 - 3 - 16 - jb["pu_y"])
+            jb = jb[jb["mvmax_y"] >= jb["mvmin_y"]]
+            if len(jb):
+                assert np.array_equal(eng.search(enc, [rows], jb), eng.search(enc, [whole], jb)), y0
+    a = eng.download_plane(whole, fr[1].shape, fr[1].dtype)
+    b = eng.download_plane(rows, fr[1].shape, fr[1].dtype)
+    assert np.array_equal(a, fr[1]) and np.array_equal(b, fr[1])
+    got = eng.search(enc, [rows], jobs)
+    exp, _ = oracle.search(fr[0], [fr[1]], jobs, bit_depth=depth)
+    assert np.array_equal(got, exp)
+    for p in (whole, rows, enc):
+        eng.release_plane(p)

@@ -70,6 +70,8 @@ def load_library() -> C.CDLL:
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
     L.x265amd_plane_device_ptr.restype = vp
     L.x265amd_plane_release.argtypes = [vp, ci]
+    L.x265amd_plane_create.argtypes = [vp, ci, ci, ci, ci, C.c_ssize_t, ci, ci, cip]
+    L.x265amd_plane_update_rows.argtypes = [vp, ci, vp, C.c_ssize_t, ci, ci]
     L.x265amd_plane_download.argtypes = [vp, ci, ci, vp, C.c_size_t]
     L.x265amd_lowres_create.argtypes = [vp, ci, cip]
     L.x265amd_lowres_update.argtypes = [vp, ci, ci]
@@ -154,6 +156,19 @@ class Engine:
         self._chk(self.lib.x265amd_plane_wrap_device(self.h, dev_ptr, width, height, margin, margin, stride,
                                                      bytes_per_px, bit_depth, C.byref(pid)))
         return pid.value
+
+    def create_plane(self, width: int, height: int, bytes_per_px: int = 1, bit_depth=None, margin: int = MARGIN) -> int:
+        """an empty device plane of the usual geometry (stride = width + 2 * margin), to be filled row by row"""
+        pid = C.c_int(-1)
+        depth = bit_depth if bit_depth is not None else (8 if bytes_per_px == 1 else 10)
+        self._chk(self.lib.x265amd_plane_create(self.h, width, height, margin, margin, width + 2 * margin, bytes_per_px,
+                                                depth, C.byref(pid)))
+        return pid.value
+
+    def update_plane_rows(self, pid: int, picture: np.ndarray, y0: int, n_rows: int):
+        """copy rows [y0, y0 + n_rows) of an UNPADDED picture array into the plane and extend their borders"""
+        assert picture.flags["C_CONTIGUOUS"]
+        self._chk(self.lib.x265amd_plane_update_rows(self.h, pid, picture.ctypes.data, picture.shape[1], y0, n_rows))
 
     def release_plane(self, pid: int):
         self._chk(self.lib.x265amd_plane_release(self.h, pid))

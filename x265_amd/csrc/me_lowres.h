@@ -66,6 +66,29 @@ __global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo
 }
 
 // ------------------------------------------------------------------------------------------
+// Border extension of freshly written picture rows [y0, y0 + n): their left / right margins, plus
+// the top margin if y0 == 0 and the bottom margin if the rows end the picture - what FrameFilter does
+// on the host before it publishes a reconstructed row (encoder/framefilter.cpp:201-262,
+// Lib/TLibCommon/TComPicYuv.cpp:259-286).  Every margin pixel is the nearest picture pixel, read
+// from the interior directly, so the order of the writes does not matter.  `org` = pixel (0,0).
+template <typename PIX>
+__global__ void __launch_bounds__(256) k_extend_rows(PIX *org, int stride, int width, int height, int mx, int my,
+                                                     int y0, int n)
+{
+    const int first = y0 == 0 ? -my : y0, last = y0 + n == height ? height + my : y0 + n;     // padded rows [first, last)
+    const int pw = width + 2 * mx;
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (t >= (last - first) * pw)
+        return;
+    const int y = first + t / pw, x = t % pw - mx;
+    if (x >= 0 && x < width && y >= 0 && y < height)
+        return;                                     // interior: just written by the caller
+    const int cy = y < 0 ? 0 : y > height - 1 ? height - 1 : y;
+    const int cx = x < 0 ? 0 : x > width - 1 ? width - 1 : x;
+    org[(int64_t)y * stride + x] = org[(int64_t)cy * stride + cx];
+}
+
+// ------------------------------------------------------------------------------------------
 // Whole-frame lookahead search.  The reference walks the 8x8 CUs of the half-resolution frame in
 // reverse raster order on one thread; a CU's predictor and candidates are the MVs of its right,
 // lower, lower-left and lower-right neighbours.  Here one wavefront owns one CU ROW and walks it

@@ -836,6 +836,59 @@ int x265amd_plane_wrap_device(x265amd_ctx *c, void *dev_base, int width, int hei
     return add_plane(c, dev_base, nullptr, width, height, margin_x, margin_y, stride, bpp, depth, plane_id);
 }
 
+int x265amd_plane_create(x265amd_ctx *c, int width, int height, int margin_x, int margin_y, intptr_t stride, int bpp,
+                         int depth, int *plane_id)
+{
+    if (!c || !plane_id)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_plane_args(c, width, height, margin_x, margin_y, stride, bpp, depth))
+        return rc;
+    size_t bytes = (size_t)(height + 2 * margin_y) * stride * bpp;
+    void *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, bytes + 64));
+    hipError_t e = hipMemsetAsync(d, 0, bytes + 64, c->stream);
+    if (e != hipSuccess)
+    {
+        hipFree(d);
+        return fail(c, X265AMD_ERR_HIP, "plane clear", e);
+    }
+    int rc = add_plane(c, d, d, width, height, margin_x, margin_y, stride, bpp, depth, plane_id);
+    if (rc)
+        hipFree(d);
+    return rc;
+}
+
+int x265amd_plane_update_rows(x265amd_ctx *c, int id, const void *host_origin, intptr_t host_stride, int y0, int n_rows)
+{
+    if (!c || !host_origin || id < 0 || id >= MAX_PLANES || !c->used[id])
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const PlaneDesc &d = c->h_planes[id];
+    if (d.lr_step || y0 < 0 || n_rows <= 0 || y0 + n_rows > d.height || host_stride < d.width)
+        return fail(c, X265AMD_ERR_INVALID, "bad row range (or a half-resolution set)");
+    char *org = (char*)const_cast<void*>(d.origin);
+    HIPCHK(c, hipMemcpy2DAsync(org + (size_t)y0 * d.stride * d.bpp, (size_t)d.stride * d.bpp,
+                               (const char*)host_origin + (size_t)y0 * host_stride * d.bpp, (size_t)host_stride * d.bpp,
+                               (size_t)d.width * d.bpp, (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+    const int first = y0 == 0 ? -d.margin_y : y0, last = y0 + n_rows == d.height ? d.height + d.margin_y : y0 + n_rows;
+    const int threads = (last - first) * (d.width + 2 * d.margin_x);
+    const dim3 grid((threads + 255) / 256), block(256);
+    if (d.bpp == 1)
+        hipLaunchKernelGGL(k_extend_rows<uint8_t>, grid, block, 0, c->stream, (uint8_t*)org, d.stride, d.width, d.height,
+                           d.margin_x, d.margin_y, y0, n_rows);
+    else
+        hipLaunchKernelGGL(k_extend_rows<uint16_t>, grid, block, 0, c->stream, (uint16_t*)org, d.stride, d.width, d.height,
+                           d.margin_x, d.margin_y, y0, n_rows);
+    HIPCHK(c, hipGetLastError());
+    // the host rows are borrowed only during the call when they are pageable; a pinned source must stay
+    // valid until the stream reaches the copy, so wait here: row publishing is a per-CTU-row event
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 void *x265amd_plane_device_ptr(x265amd_ctx *c, int id)
 {
     if (!c || id < 0 || id >= MAX_PLANES || !c->used[id])

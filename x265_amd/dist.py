@@ -49,6 +49,14 @@ def broadcast_plane(plane: torch.Tensor, src: int = 0, engine=None) -> torch.Ten
     return plane
 
 
+def broadcast_plane_rows(plane: torch.Tensor, first_row: int, n_rows: int, src: int = 0, engine=None) -> torch.Tensor:
+    """The same for rows [first_row, first_row + n_rows) of the PADDED plane tensor only (a contiguous
+    slice): the exchange step of row-wise publishing, where the owner of a reconstructed picture hands
+    out each CTU row (with its extended borders) as soon as it is final."""
+    broadcast_plane(plane[first_row:first_row + n_rows], src=src, engine=engine)
+    return plane
+
+
 class PlaneRing:
     """Reference planes arriving one per frame, each broadcast from its owner into one of two
     buffers.  Per frame k the caller runs
