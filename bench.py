@@ -200,8 +200,13 @@ def main():
         eng.eval_count(reset=True)
         barrier()
         trace("timed region starts")
+        # HIP events bracket the kernels of the LAST step only: timestamp events drain the queue between
+        # launches, and with them in every step the back-to-back frames run about 7 % slower
+        eng.set_timing(False)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
+            if k == steps - 1:
+                eng.set_timing(True)
             step(jl)
         eng.sync()
         barrier()
@@ -346,7 +351,8 @@ def main():
                    "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
         "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_is": "HIP-event bracket around the search kernels of the last step of the timed region"},
         "dia_search": {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
                        "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms},
         "pcie_inclusive": {"workload": "HEX+subme5 frame; enc and ref planes copied host->device and the MV/cost field "
