@@ -232,6 +232,21 @@ def main():
     alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
     achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
 
+    # ---- the same kernel against the integer-ALU roof: algorithmic operations of one frame ------------
+    # (1 SAD evaluation of a w x h block = w*h operations, 1 SATD evaluation = 5*w*h; the split per PU size
+    # comes from the evaluation counter of one run per size)
+    alg_ops = 0.0
+    for size in (16, 64):
+        js = hex_jobs[hex_jobs["w"] == size]
+        jl_s = eng.make_joblist(js)
+        eng.eval_count(reset=True)
+        jl_s.run(enc_id, [ref_id], fetch=False)
+        ev = eng.eval_count(reset=True)
+        jl_s.close()
+        satd = 17 * len(js)
+        alg_ops += ((ev - satd) + 5 * satd) * size * size
+    eng.set_timing(True)
+
     # ---- the exchange step alone (N > 1): reference plane from rank 0 to every rank ----------------
     bcast_us = None
     if world > 1:
@@ -353,6 +368,13 @@ def main():
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms_is": "HIP-event bracket around the search kernels of the last step of the timed region"},
+        # the bound that actually binds this kernel is instruction issue, not memory: the same launch against
+        # the un-packed 32-bit integer-ALU roof (CUs x 64 lanes x clock)
+        "roofline_valu": {"bound": "valu", "kernel": "k_search<uint8_t>", "achieved": alg_ops / (k_search_ms * 1e-3) / 1e12,
+                          "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s",
+                          "frac": alg_ops / (k_search_ms * 1e-3) / (cus * 64 * clk_hz),
+                          "algorithmic_ops_per_launch": alg_ops,
+                          "ops_def": "SAD evaluation = w*h, SATD evaluation = 5*w*h integer operations"},
         "dia_search": {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
                        "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms},
         "pcie_inclusive": {"workload": "HEX+subme5 frame; enc and ref planes copied host->device and the MV/cost field "
