@@ -114,6 +114,30 @@ def test_mixed_reference_kinds_in_one_batch(eng, oracle):
         eng.release_plane(p)
 
 
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (48, 48), (34, 22), (130, 18)])
+def test_lookahead_tiny_frames(eng, oracle, w, h):
+    """one CU, one row, one column, odd sizes that round up to whole CUs: every neighbour pattern of the
+    predictor chain, all methods"""
+    fr = synth.make_sequence(w, h, 2, seed=w * 100 + h)
+    src = [eng.upload_plane(f) for f in fr]
+    lr = [eng.lowres_create(s) for s in src]
+    cpu = [oracle.lowres_init(f) for f in fr]
+    g = cpu[0][0]
+    assert eng.lowres_geometry(lr[0])[3:] == (g.cu_w, g.cu_h)
+    for k in range(2):
+        for which in range(4):
+            got = eng.download_plane(lr[k], g.padded_shape, np.uint8, which=which)
+            assert np.array_equal(got[:, :g.width + 2 * synth.MARGIN], cpu[k][1][which][:, :g.width + 2 * synth.MARGIN])
+    for method in range(5):
+        for subme in (1, 7):
+            got = eng.lookahead_me([lr[0], lr[1]], [lr[1], lr[0]], merange=8, method=method, subme=subme, qp=20)
+            for i, (a, b) in enumerate(((0, 1), (1, 0))):
+                exp, _ = oracle.lookahead_me(cpu[a][1], cpu[b][1], g.cu_w, g.cu_h, 8, method, subme, 20)
+                assert np.array_equal(got[i], exp), (method, subme, i)
+    for p in lr + src:
+        eng.release_plane(p)
+
+
 def test_lowres_argument_checks(eng):
     from x265_amd.api import X265AmdError
     fr = synth.make_sequence(64, 64, 1, seed=3)

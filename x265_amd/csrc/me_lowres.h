@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_extend_rows(PIX *org, int stride, int w
 // of the neighbour it needs with device-scope atomic loads until it differs.  No fences, hence no
 // cache write-backs or invalidations.  Row y waits only on row y + 1, i.e. workgroup b only on
 // workgroup b - 1 of the same pair, which was dispatched earlier: the chain always makes progress.
-// A bounded spin guards against a lost predecessor: the row that gives up stops waiting altogether,
+// A time limit guards against a lost predecessor: the row that gives up stops waiting altogether,
 // finishes with whatever it reads, and the call reports the failure.
 struct LookPair { int32_t enc_plane, ref_plane; };
 
