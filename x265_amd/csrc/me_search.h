@@ -513,6 +513,42 @@ struct Search
         return bcost;
     }
 
+    // One refinement round (motion.cpp:799-809, 813-845, 851-861): the first n of the 8 neighbours of
+    // bmv at distance `step` (q-pel units), each subpelCompare + mvcost; improves bcost and returns
+    // the winning direction (0: none).  Candidate data goes straight into the job state - no
+    // per-candidate arrays are kept in scalar registers.
+    __device__ __forceinline__ int subpel_round(int step, int n, int kind)
+    {
+        typedef Dev<L> D;
+        // every candidate's block origin lies within [(bmv - step) >> 2, (bmv + step) >> 2]
+        const int where = W.lowres ? 0 : W.place(XA_S16(bmx - step) >> 2, XA_S16(bmy - step) >> 2,
+                                                 XA_S16(bmx + step) >> 2, XA_S16(bmy + step) >> 2, true);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const int qx = XA_S16(bmx + c_square1[k + 1][0] * step), qy = XA_S16(bmy + c_square1[k + 1][1] * step);
+            W.s->pts[k] = W.block_off(where, qx >> 2, qy >> 2);
+            W.s->lbl[k] = (qy << 16) | (qx & 0xffff);
+            W.s->frc[k] = W.phase(qx, qy);
+        }
+        W.evals += (unsigned)n;
+        const int cf = where | W.take_par(W.lowres ? 1 : n);
+        D::post(W.base, D::OP_ANY, n, cf, kind);
+        const Res8 r = D::eval_any(W.base, n, cf, kind);
+        int bdir = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const int c = uni(r.c[k]);
+            if (k < n && c < bcost)
+            {
+                bcost = c;
+                bdir = k + 1;
+            }
+        }
+        return bdir;
+    }
+
     // ---------------------------------------------------------------- the search
     __device__ __forceinline__ int run(const FullBest *fb, int fb_stride, int &outx, int &outy)
     {
@@ -824,51 +860,23 @@ struct Search
         const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
         if (wl[4])
             bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
-        // Each round prices its 4 or 8 neighbours in one call; they are then taken in the reference's
-        // order with its strict comparison.
+        // Half-pel rounds (step 2), then quarter-pel rounds (step 1), through one code path.  Each round
+        // prices its 4 or 8 neighbours in one call; they are then taken in the reference's order with
+        // its strict comparison.
 #pragma nounroll
-        for (int it = 0; it < wl[0]; it++)
+        for (int ph = 0; ph < 2; ph++)
         {
-            int qx[8], qy[8], c[8], bdir = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-            {
-                qx[i] = XA_S16(bmx + c_square1[i + 1][0] * 2);
-                qy[i] = XA_S16(bmy + c_square1[i + 1][1] * 2);
-            }
-            W.subpel_cost8(wl[1], qx, qy, hkind, c);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i < wl[1] && c[i] < bcost)
-                {
-                    bcost = c[i];
-                    bdir = i + 1;
-                }
-            bmx = XA_S16(bmx + c_square1[bdir][0] * 2);
-            bmy = XA_S16(bmy + c_square1[bdir][1] * 2);
-        }
-        if (!wl[4])
-            bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
+            const int iters = ph ? wl[2] : wl[0], dirs = ph ? wl[3] : wl[1], step = ph ? 1 : 2;
+            const int kind = ph ? X265AMD_SATD : hkind;
+            if (ph && !wl[4])
+                bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);     // hpel used SAD: remeasure with SATD (motion.cpp:848)
 #pragma nounroll
-        for (int it = 0; it < wl[2]; it++)
-        {
-            int qx[8], qy[8], c[8], bdir = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
+            for (int it = 0; it < iters; it++)
             {
-                qx[i] = XA_S16(bmx + c_square1[i + 1][0]);
-                qy[i] = XA_S16(bmy + c_square1[i + 1][1]);
+                const int bdir = subpel_round(step, dirs, kind);
+                bmx = XA_S16(bmx + c_square1[bdir][0] * step);
+                bmy = XA_S16(bmy + c_square1[bdir][1] * step);
             }
-            W.subpel_cost8(wl[3], qx, qy, X265AMD_SATD, c);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i < wl[3] && c[i] < bcost)
-                {
-                    bcost = c[i];
-                    bdir = i + 1;
-                }
-            bmx = XA_S16(bmx + c_square1[bdir][0]);
-            bmy = XA_S16(bmy + c_square1[bdir][1]);
         }
         W.stamp(5);
         outx = bmx;
