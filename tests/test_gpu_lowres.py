@@ -55,7 +55,7 @@ def test_lookahead_path_matches_reference_vectors(eng, bits):
         eng.release_plane(p)
 
 
-@pytest.mark.parametrize("bits,w,h", [(8, 1920, 1080), (16, 832, 480), (8, 176, 144)])
+@pytest.mark.parametrize("bits,w,h", [(8, 1920, 1080), (16, 832, 480), (8, 176, 144), (16, 3840, 2160)])
 def test_lookahead_frames_match_oracle(eng, oracle, bits, w, h):
     """several frame pairs in one call (B-frame style: both directions), reference defaults
     (HEX, subme 1, merange 16), planes re-initialised in place for a second round"""
