@@ -1092,6 +1092,63 @@ struct Dev
             res += (v.lane == k) ? (am == 1 ? acc[k] >> 1 : acc[k]) : 0;
     }
 
+    // The same for PUs of at most 16 groups on a single wavefront (8x8 and smaller: the lookahead's
+    // CUs): the PU occupies one 16-lane row, so four candidates are priced side by side, one per row,
+    // instead of one after the other in the same lanes.
+    static __device__ __forceinline__ void lr_batch_rows(View &v, const Src &src, int kind, int n, int &res)
+    {
+        const int w = uni(v.s->w), h = uni(v.s->h), pitch = v.s->stride, step_lr = v.s->lrstep;
+        const int am = accum_mode(kind, w, h);
+        const int row = v.lane >> 4, gl = v.lane & 15;
+        const bool in_pu = gl < v.G;
+        const int gv = v.l->gxy[in_pu ? gl : 0], lo = (gv >> 8) * pitch + (gv & 0xff);
+        uint32_t fd[2] = { 0, 0 };
+        fd[0] = v.l->fenc[DW * (in_pu ? gl : 0)];
+        if (DW == 2)
+            fd[1] = v.l->fenc[DW * (in_pu ? gl : 0) + 1];
+        const P4 f = unpack4(fd);
+        for (int c0 = 0; c0 < n; c0 += 4)
+        {
+            const int k = c0 + row;
+            const bool act = in_pu && k < n;
+            const int kk = k < n ? k : 0;
+            const int off = v.s->pts[kk], fr = v.s->frc[kk];
+            const bool avg = (fr & 0x10) != 0;
+            const int offb = avg ? off + ((fr >> 5) & 1) + ((fr >> 6) & 1) * pitch : off;
+            uint32_t a[2], b[2];
+            src.rd4_plane(off + lo, (fr & 3) * step_lr, a);
+            src.rd4_plane(offb + lo, (avg ? (fr >> 2) & 3 : fr & 3) * step_lr, b);
+            P4 r;
+            if (DW == 1)
+            {
+                a[0] = __builtin_amdgcn_lerp(a[0], b[0], 0x01010101u);
+                r = unpack4(a);
+            }
+            else
+            {
+                const P4 pa = unpack4(a), pb = unpack4(b);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    r.v[i] = (pa.v[i] + pb.v[i] + 1) >> 1;
+            }
+            int d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                d[i] = act ? f.v[i] - r.v[i] : 0;
+            int a0 = 0;
+            accum(am, d, v.lane, a0, a0);
+            int tot = sum16(a0);                        // the row's (= the candidate's) total in every lane of the row
+            if (am == 1)
+                tot >>= 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int t = __builtin_amdgcn_readlane(tot, 16 * q);
+                res += (v.lane == c0 + q) ? t : 0;
+            }
+        }
+    }
+
     // eval_any: any cost kind, each candidate with its own phase (JobState::frc), one cost_body per
     // candidate (half-resolution reference sets: one batch, lr_batch).
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_)
@@ -1105,7 +1162,8 @@ struct Dev
         int par = (cflags & CF_PAR) ? 1 : 0;
         if (L::LR && (uni(v.s->frc[0]) & LR_FLAG))
         {
-            if (n == 1)      lr_batch<1>(v, src, kind, par, res);
+            if (NW == 1 && v.G <= 16) lr_batch_rows(v, src, kind, n, res);
+            else if (n == 1) lr_batch<1>(v, src, kind, par, res);
             else if (n <= 4) lr_batch<4>(v, src, kind, par, res);
             else             lr_batch<8>(v, src, kind, par, res);
             Res8 r;
