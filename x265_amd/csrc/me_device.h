@@ -768,6 +768,40 @@ struct Dev
         }
     }
 
+    // SADs of n candidates of a PU of at most 16 groups: candidate c0 + row in 16-lane row `row`;
+    // lane k of `res` receives the SAD of candidate k.
+    template <bool LW>
+    static __device__ __forceinline__ void sad_rows(const View &v, const Src &src, int pitch, int n, int &res)
+    {
+        const int row = v.lane >> 4, gl = v.lane & 15;
+        const bool in_pu = gl < v.G;
+        const int gv = v.l->gxy[in_pu ? gl : 0];
+        const int lo = (gv >> 8) * pitch + (gv & 0xff) * (LW ? PB : 1);
+        uint32_t f[2];
+        f[0] = v.l->fenc[DW * (in_pu ? gl : 0)];
+        if (DW == 2)
+            f[1] = v.l->fenc[DW * (in_pu ? gl : 0) + 1];
+        for (int c0 = 0; c0 < n; c0 += 4)
+        {
+            const int k = c0 + row;
+            const int off = v.s->pts[k < n ? k : 0];
+            uint32_t r[2];
+            src.template rd4_packed<LW>(off + lo, r);
+            int sad;
+            if (DW == 1)
+                sad = __builtin_amdgcn_sad_u8(f[0], r[0], 0);
+            else
+                sad = __builtin_amdgcn_sad_u16(f[1], r[1], __builtin_amdgcn_sad_u16(f[0], r[0], 0));
+            const int tot = sum16((in_pu && k < n) ? sad : 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int t = __builtin_amdgcn_readlane(tot, 16 * q);
+                res += (v.lane == c0 + q) ? t : 0;
+            }
+        }
+    }
+
     // 4 prediction pixels of one group for interpolation mode `mode` / phase (xf,yf); filters follow
     // common/ipfilter.cpp with hr = 14 - depth.  `off` addresses the group's first pixel in the
     // candidate block; PRED_HV reads the horizontally filtered intermediate from LDS (stage_hv) at
@@ -993,6 +1027,18 @@ struct Dev
 #pragma unroll
         for (int k = 0; k < 8; k++)
             p[k] = v.s->pts[k];             // (entries >= n repeat candidate 0)
+        if (NW == 1 && n > 1 && v.G <= 16)
+        {
+            // small PU (8x8 and below) on its own wavefront: four candidates side by side, one per 16-lane row
+            int res = mv;
+            if (lw) sad_rows<true>(v, src, pitch, n, res);
+            else    sad_rows<false>(v, src, pitch, n, res);
+            Res8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                r.c[k] = __builtin_amdgcn_readlane(res, k);
+            return r;
+        }
         int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (n == 1)
         {
