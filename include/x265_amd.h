@@ -191,6 +191,11 @@ int x265amd_joblist_create(x265amd_ctx *ctx, const x265amd_me_job *jobs, int n, 
 int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
                         x265amd_me_result *out);
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
+/* Reorder the list's launches so that the jobs that took the most block-cost evaluations in its last
+ * run start first (results do not depend on the order; a launch ends with its longest searches, and
+ * consecutive frames move alike).  Blocks until the last run has finished.  No counterpart in the
+ * reference, whose CTU rows are load-balanced by its thread pool (common/threadpool.cpp). */
+int x265amd_joblist_rebalance(x265amd_ctx *ctx, x265amd_joblist *list);
 int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
 
 /* ---- lookahead: whole-frame motion search ------------------------------------------------

@@ -365,3 +365,26 @@ def test_rowwise_published_plane_equals_whole_upload(eng, oracle, bits):
     assert np.array_equal(got, exp)
     for p in (whole, rows, enc):
         eng.release_plane(p)
+
+
+def test_joblist_rebalance_keeps_results(eng, oracle):
+    """reordering a planned list by the last run's job lengths changes the launch order only"""
+    fr = synth.make_sequence(416, 240, 3, seed=21)
+    ids = [eng.upload_plane(f) for f in fr]
+    jobs = np.concatenate([J.frame_jobs(416, 240, sizes=(64, 32, 16, 8), method=m, subme=3, merange=32, qp=28)
+                           for m in (J.HEX, J.STAR)])
+    jl = eng.make_joblist(jobs)
+    jl.rebalance()                                    # before any run: a no-op
+    a = jl.run(ids[0], [ids[1]])
+    jl.rebalance()
+    b = jl.run(ids[0], [ids[1]])
+    c = jl.run(ids[2], [ids[1]])                      # another picture with the order learnt from the first
+    jl.rebalance()
+    d = jl.run(ids[2], [ids[1]])
+    jl.close()
+    exp, _ = oracle.search(fr[0], [fr[1]], jobs, threads=4)
+    exp2, _ = oracle.search(fr[2], [fr[1]], jobs, threads=4)
+    assert np.array_equal(a, exp) and np.array_equal(b, exp)
+    assert np.array_equal(c, exp2) and np.array_equal(d, exp2)
+    for i in ids:
+        eng.release_plane(i)

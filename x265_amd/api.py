@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
     L.x265amd_joblist_results_device.argtypes = [vp]
     L.x265amd_joblist_results_device.restype = vp
     L.x265amd_joblist_destroy.argtypes = [vp, vp]
+    L.x265amd_joblist_rebalance.argtypes = [vp, vp]
     L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
     L.x265amd_set_timing.argtypes = [vp, ci]
     L.x265amd_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -277,6 +278,10 @@ class JobList:
         self.eng._chk(self.eng.lib.x265amd_joblist_run(self.eng.h, self.h, enc_plane, refs, len(ref_planes),
                                                        out.ctypes.data if fetch else None))
         return out
+
+    def rebalance(self):
+        """start the jobs that were longest in the last run first in the following runs"""
+        self.eng._chk(self.eng.lib.x265amd_joblist_rebalance(self.eng.h, self.h))
 
     @property
     def results_device_ptr(self) -> int:

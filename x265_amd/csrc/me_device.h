@@ -682,9 +682,9 @@ struct Dev
         bsync();
     }
 
-    // one lane publishes the job's result and evaluation count
+    // one lane publishes the job's result and evaluation count (hist: optional per-job record of the count)
     static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost,
-                                                unsigned long long *evals, unsigned n_evals)
+                                                unsigned long long *evals, unsigned n_evals, unsigned *hist)
     {
         if (threadIdx.x == 0)
         {
@@ -694,6 +694,8 @@ struct Dev
             r.cost = cost;
             *out = r;
             atomicAdd(evals, (unsigned long long)n_evals);
+            if (hist)
+                *hist = n_evals;            // the job's length, for the next run's launch order
         }
     }
 

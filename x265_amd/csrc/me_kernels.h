@@ -16,6 +16,7 @@ struct BatchParams
     int32_t          ref_planes[X265AMD_MAX_REFS];
     int32_t          n_refs;
     int32_t          flags;               // JF_* bits applied to every job (tuning aids)
+    unsigned        *hist;                // optional: evaluations spent on job i, written to hist[i]
 };
 
 // Does the dedicated exhaustive kernel handle this job?  (SAD metric, bounded range)
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
     int cost = S.run(f, fb_stride, ox, oy);
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     // (evaluation counts go to one of EVAL_SLOTS counters, 128 bytes apart, to spread the atomics)
-    Dev<L>::publish(out + id, ox, oy, cost, evals + (blockIdx.x % EVAL_SLOTS) * 16, W.evals);
+    Dev<L>::publish(out + id, ox, oy, cost, evals + (blockIdx.x % EVAL_SLOTS) * 16, W.evals, P.hist ? P.hist + id : nullptr);
 #ifdef XA_PROFILE
     W.stamp(6);
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)      // (a sample: every job would serialise on the atomics)

@@ -84,7 +84,9 @@ struct x265amd_ctx
 struct x265amd_joblist
 {
     int     n = 0, bpp = 1;
-    DevBuf  jobs, results, fb, items, item_jobs, idx;
+    DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
+    std::vector<int> order;               // host copy of idx
+    bool    ran = false;
     int     cls_count[JOB_CLASSES] = { 0, 0, 0 };   // job classes of the general kernel: idx = [class 0..., class 1..., class 2...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
@@ -526,14 +528,20 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
                 if (job_class(jobs[i].w, jobs[i].h) == cls)
                     seg.push_back(i);
             L->cls_count[cls] = (int)seg.size();
-            std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
-                return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
-                       std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
-            xcd_interleave(seg);
+            if (!(c->flags & 8))        // (tuning aid: X265AMD_FLAGS bit 3 keeps the caller's job order)
+            {
+                std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                    return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
+                           std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
+                xcd_interleave(seg);
+            }
             order.insert(order.end(), seg.begin(), seg.end());
         }
         if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
         HIPCHK(c, hipMemcpy(L->idx.p, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        if (int rc = ensure(c, L->hist, (size_t)n * sizeof(unsigned))) return rc;
+        HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
+        L->order = order;
     }
     std::vector<PlannedItem> planned;
     {
@@ -611,7 +619,7 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx };
+    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -656,8 +664,11 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
 }
 
 // the general-kernel launches of a planned list
-int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P, bool timing_events)
+int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P0, bool timing_events)
 {
+    BatchParams P = P0;
+    P.hist = (unsigned*)L->hist.p;
+    L->ran = true;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
                           L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
@@ -1293,6 +1304,42 @@ int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *L)
 {
     return L ? (const x265amd_me_result*)L->results.p : nullptr;
+}
+
+// Launch order by job length.  A pattern search's length is data dependent (a far-moving block takes
+// three times the evaluations of a still one) and the general kernel's launch ends with its longest
+// jobs; starting those first shortens the launch.  The lengths are those of the list's last run -
+// consecutive frames of a sequence move alike - grouped coarsely so that jobs of similar length keep
+// their picture order and XCD banding.
+int x265amd_joblist_rebalance(x265amd_ctx *c, x265amd_joblist *L)
+{
+    if (!c || !L)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!L->ran || L->n == 0)
+        return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned> hist(L->n);
+    HIPCHK(c, hipMemcpy(hist.data(), L->hist.p, (size_t)L->n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int off = 0;
+    for (int cls = 0; cls < JOB_CLASSES; cls++)
+    {
+        const int cnt = L->cls_count[cls];
+        if (cnt > 1)
+        {
+            unsigned mx = 1;
+            for (int i = 0; i < cnt; i++)
+                mx = std::max(mx, hist[L->order[off + i]]);
+            // 8 length groups, longest first; inside a group the planned (picture / XCD band) order stays
+            auto group = [&](int id) { return 7 - (int)((uint64_t)hist[id] * 8 / ((uint64_t)mx + 1)); };
+            std::stable_sort(L->order.begin() + off, L->order.begin() + off + cnt,
+                             [&](int a, int b) { return group(a) < group(b); });
+        }
+        off += cnt;
+    }
+    HIPCHK(c, hipMemcpy(L->idx.p, L->order.data(), (size_t)L->n * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
 }
 
 int x265amd_joblist_destroy(x265amd_ctx *c, x265amd_joblist *L)
