@@ -1197,6 +1197,97 @@ struct Dev
         }
     }
 
+    // Any cost kind / phase for PUs of at most 16 groups of 8-bit pixels on a single wavefront: four
+    // candidates side by side, one per 16-lane row, all through ONE prediction path - the two-pass
+    // (horizontal to 16-bit, then vertical) filter with the identity taps of phase 0 where a direction
+    // is not fractional.  At 8-bit depth that path equals the reference's one-pass filters bit for bit:
+    // the intermediate is 64 p - 8192 (or sum_h - 8192), no 16-bit cast bites, and
+    // (64 S + 2048) >> 12 == (S + 32) >> 6 (common/ipfilter.cpp:38-139, 265-309, 354-425 with headRoom 6).
+    static __device__ __forceinline__ int sel4(int f, int a, int b, int c, int d)
+    {
+        return f == 0 ? a : f == 1 ? b : f == 2 ? c : d;
+    }
+    template <bool LW>
+    static __device__ __forceinline__ void subpel_rows(View &v, const Src &src, int pitch, int kind, int n, int &res)
+    {
+        static_assert(DW == 1, "8-bit pixels only");
+        constexpr int step = LW ? PB : 1;
+        const int w = uni(v.s->w), h = uni(v.s->h), ngx = w >> 2;
+        const int per = (h + 7) * ngx;                  // intermediate groups (4 values each) per candidate
+        const int lg = ngx == 1 ? 0 : ngx == 2 ? 1 : 2; // log2 of the groups per row (PU widths 4, 8, 16)
+        const int am = accum_mode(kind, w, h);
+        const int row = v.lane >> 4, gl = v.lane & 15;
+        const bool in_pu = gl < v.G;
+        const int gv = v.l->gxy[in_pu ? gl : 0], gx = gv & 0xff, gy = gv >> 8;
+        uint32_t fd[2] = { v.l->fenc[in_pu ? gl : 0], 0 };
+        const P4 f = unpack4(fd);
+        for (int c0 = 0; c0 < n; c0 += 4)
+        {
+            // horizontal pass, one candidate after the other: rows -3 .. h+3, one 4-value group per lane
+            // ((h + 7) * w / 4 <= 44 groups for every PU of at most 16 groups)
+            const int lr = v.lane >> lg, col = (v.lane & (ngx - 1)) * 4;
+#pragma nounroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int kk = c0 + q < n ? c0 + q : 0;
+                const int off = v.s->pts[kk], xf = v.s->frc[kk] & 3;
+                if (v.lane < per)
+                {
+                    uint32_t px[6];
+                    src.template rd12_packed<LW>(off + (lr - 3) * pitch + (col - 3) * step, px);
+                    const int lo = sel4(xf, c_luma_b4[0][0], c_luma_b4[1][0], c_luma_b4[2][0], c_luma_b4[3][0]);
+                    const int hi = sel4(xf, c_luma_b4[0][1], c_luma_b4[1][1], c_luma_b4[2][1], c_luma_b4[3][1]);
+                    const uint32_t b0 = px[0] ^ 0x80808080u, b1 = px[1] ^ 0x80808080u, b2 = px[2] ^ 0x80808080u;
+                    int sm[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const uint32_t a = i ? __builtin_amdgcn_alignbyte(b1, b0, i) : b0;
+                        const uint32_t b = i ? __builtin_amdgcn_alignbyte(b2, b1, i) : b1;
+                        // (8192 from the -128 pixel bias and -8192 of the intermediate's offset cancel)
+                        sm[i] = __builtin_amdgcn_sdot4((int)b, hi, __builtin_amdgcn_sdot4((int)a, lo, 0, false), false);
+                    }
+                    const uint32_t p01 = __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100), p23 = __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100);
+                    *(XA_LDS uint64_t*)(v.l->imm + (q * per + v.lane) * 4) = (uint64_t)p01 | ((uint64_t)p23 << 32);
+                }
+            }
+            bsync();
+            // vertical pass + cost: candidate c0 + row in lane row `row`
+            const int k = c0 + row, kk = k < n ? k : 0;
+            const int yf = (v.s->frc[kk] >> 2) & 3;
+            int tp[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                tp[i] = sel4(yf, c_luma_h2[0][i], c_luma_h2[1][i], c_luma_h2[2][i], c_luma_h2[3][i]);
+            const XA_LDS int16_t *m = v.l->imm + (row * per + gy * ngx) * 4 + gx;
+            int sum[4] = { 2048 + 524288, 2048 + 524288, 2048 + 524288, 2048 + 524288 };
+#pragma unroll
+            for (int t = 0; t < 8; t += 2)
+            {
+                const uint64_t d0 = *(const XA_LDS uint64_t*)(m + t * w);
+                const uint64_t d1 = *(const XA_LDS uint64_t*)(m + (t + 1) * w);
+                const uint32_t a[2] = { (uint32_t)d0, (uint32_t)(d0 >> 32) }, b[2] = { (uint32_t)d1, (uint32_t)(d1 >> 32) };
+                vpair16(a, b, tp[t / 2], sum);
+            }
+            int d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                d[i] = (in_pu && k < n) ? f.v[i] - clamp_pix(sum[i] >> 12, 255) : 0;
+            int a0 = 0;
+            accum(am, d, v.lane, a0, a0);
+            int tot = sum16(a0);
+            if (am == 1)
+                tot >>= 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int t = __builtin_amdgcn_readlane(tot, 16 * q);
+                res += (v.lane == c0 + q) ? t : 0;
+            }
+            bsync();                                    // the intermediate is reused by the next four
+        }
+    }
+
     // eval_any: any cost kind, each candidate with its own phase (JobState::frc), one cost_body per
     // candidate (half-resolution reference sets: one batch, lr_batch).
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_)
@@ -1219,6 +1310,20 @@ struct Dev
             for (int k = 0; k < 8; k++)
                 r.c[k] = __builtin_amdgcn_readlane(res, k);
             return r;
+        }
+        if constexpr (NW == 1 && DW == 1)
+        {
+            const int pw = uni(v.s->w);
+            if (n > 1 && v.G <= 16 && (pw & (pw - 1)) == 0)     // (widths 4, 8, 16: a power-of-two number of groups per row)
+            {
+                if (lw) subpel_rows<true>(v, src, pitch, kind, n, res);
+                else    subpel_rows<false>(v, src, pitch, kind, n, res);
+                Res8 r;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    r.c[k] = __builtin_amdgcn_readlane(res, k);
+                return r;
+            }
         }
         HvCache hc = { 0, 0, false };
         for (int k = 0; k < n; k++)
