@@ -76,6 +76,7 @@ struct x265amd_ctx
     static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
+    x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
     hipStream_t lane(int k) const { return (k % (N_AUX + 1)) == 0 ? stream : aux[(k % (N_AUX + 1)) - 1]; }
 };
 
@@ -515,6 +516,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 {
     L->n = n;
     L->bpp = bpp;
+    L->launches.clear();
+    L->ran = false;
     if (int rc = ensure(c, L->jobs, (size_t)n * sizeof(x265amd_me_job))) return rc;
     if (int rc = ensure(c, L->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
     HIPCHK(c, hipMemcpyAsync(L->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
@@ -775,6 +778,11 @@ void x265amd_destroy(x265amd_ctx *c)
     for (int i = 0; i < MAX_PLANES; i++)
         if (c->used[i] && c->owned[i])
             hipFree(c->owned[i]);
+    if (c->batch_list)
+    {
+        joblist_free(c, c->batch_list);
+        c->batch_list = nullptr;
+    }
     DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs,
                        &c->look_pairs, &c->look_results, &c->look_progress };
     for (DevBuf *b : bufs)
@@ -1225,7 +1233,9 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
     if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
     if (int rc = check_job_ranges(c, enc_plane, ref_planes, jobs, n)) return rc;
     if (int rc = sync_planes(c)) return rc;
-    x265amd_joblist *L = new x265amd_joblist;
+    if (!c->batch_list)
+        c->batch_list = new x265amd_joblist;
+    x265amd_joblist *L = c->batch_list;
     int rc = joblist_build(c, L, jobs, n, c->h_planes[enc_plane].bpp);
     if (!rc)
     {
@@ -1240,7 +1250,6 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
         if (e != hipSuccess)
             rc = fail(c, X265AMD_ERR_HIP, "result download", e);
     }
-    joblist_free(c, L);
     return rc;
 }
 
