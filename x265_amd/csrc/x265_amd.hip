@@ -88,6 +88,7 @@ struct x265amd_joblist
     DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
+    bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
     int     cls_count[JOB_CLASSES] = { 0, 0, 0 };   // job classes of the general kernel: idx = [class 0..., class 1..., class 2...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
@@ -541,10 +542,13 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
             order.insert(order.end(), seg.begin(), seg.end());
         }
         if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
-        HIPCHK(c, hipMemcpy(L->idx.p, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        if (int rc = ensure(c, L->hist, (size_t)n * sizeof(unsigned))) return rc;
-        HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
-        L->order = order;
+        L->order.swap(order);           // (the list keeps the host copy: it outlives the asynchronous upload)
+        HIPCHK(c, hipMemcpyAsync(L->idx.p, L->order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (L->keep_hist)
+        {
+            if (int rc = ensure(c, L->hist, (size_t)n * sizeof(unsigned))) return rc;
+            HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
+        }
     }
     std::vector<PlannedItem> planned;
     {
@@ -670,7 +674,7 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
 int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P0, bool timing_events)
 {
     BatchParams P = P0;
-    P.hist = (unsigned*)L->hist.p;
+    P.hist = L->keep_hist ? (unsigned*)L->hist.p : nullptr;
     L->ran = true;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
@@ -1234,7 +1238,10 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
     if (int rc = check_job_ranges(c, enc_plane, ref_planes, jobs, n)) return rc;
     if (int rc = sync_planes(c)) return rc;
     if (!c->batch_list)
+    {
         c->batch_list = new x265amd_joblist;
+        c->batch_list->keep_hist = false;
+    }
     x265amd_joblist *L = c->batch_list;
     int rc = joblist_build(c, L, jobs, n, c->h_planes[enc_plane].bpp);
     if (!rc)
