@@ -259,14 +259,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         bcast_us = float(t.item())
 
-    if args.only_primary:
+    # With N > 1 only the leg `value` is quoted on runs (plus the broadcast alone): the secondary legs are
+    # single-GPU figures, and every extra step on N ranks is one more collective per rank for nothing.
+    if args.only_primary or world > 1:
         if rank == 0:
-            print(json.dumps({"metric": "ME block-cost evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-                              "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs,
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                                           "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes},
-                              "note": "reduced line of --only-primary"}), flush=True)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("k_search_u8_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            print(json.dumps({
+                "metric": "ME block-cost evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                "frames_per_s": world * args.steps / dt, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 hpel + 8 qpel SATD), PUs 16x16+64x64 "
+                                       "(BASELINE configs[1]); one frame per GPU per step; reference plane broadcast from rank 0",
+                           "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": evals / (args.steps * world),
+                           "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world,
+                           "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
+                "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                             "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                             "kernel_ms_is": "HIP-event bracket around the search kernels of the last step of the timed region"},
+                "cpu_baseline": None,
+                "note": "primary leg only (--only-primary, or N > 1: cpu_baseline and the secondary legs are reported at N = 1)"}),
+                flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
