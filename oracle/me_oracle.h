@@ -12,6 +12,13 @@
  * tests/golden/ that were generated from that compiled reference by
  * oracle/gen_golden.py.
  *
+ * Two call-site loops live in translation units that cannot be linked without the whole
+ * encoder (encoder/slicetype.cpp, Lib/TLibEncoder/TEncSearch.cpp): the lookahead's neighbour-
+ * predicted CU scan and the bidirectional refinement's xPatternSearch / xPatternRefinement.  For
+ * those the golden vectors come from the reference's own MotionEstimate / primitives / filters /
+ * MV costs driven by a restated loop in oracle/ref_shim.cpp: the arithmetic is pinned, the two
+ * short control loops are restated on both sides.
+ *
  * Every function cites the reference file:line it restates.
  */
 #ifndef ME_ORACLE_H
