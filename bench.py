@@ -172,7 +172,20 @@ def main():
     trace("job lists planned")
     from x265_amd import dist as xd
 
-    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=bool(os.environ.get("X265AMD_OVERLAP_BROADCAST")))
+    if os.environ.get("X265AMD_BENCH_TRACE"):       # a watchdog: what is busy when a rank stops making progress
+        import threading
+
+        def watchdog():
+            for _ in range(3):
+                time.sleep(int(os.environ.get("X265AMD_BENCH_WATCH_S", "25")))
+                cur = torch.cuda.current_stream(dev)
+                ev = lambda e: "-" if e is None else ("done" if e.query() else "BUSY")
+                trace("watchdog: engine {%s}; torch current stream %s; ring free %s filled %s ready %d"
+                      % (eng.debug_state(), "done" if cur.query() else "BUSY", [ev(e) for e in ring.free],
+                         [ev(e) for e in ring.filled], ring.ready))
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=not os.environ.get("X265AMD_NO_OVERLAP"))
     step_no = [0]
 
     def step(jl):

@@ -67,6 +67,17 @@ const char *x265amd_last_error(const x265amd_ctx *ctx);
 int  x265amd_sync(x265amd_ctx *ctx);
 /* the hipStream_t the context launches on (for callers that time or order against it) */
 void *x265amd_stream(x265amd_ctx *ctx);
+/* developer aid: one line of text saying which of the context's streams and fork / join events are still
+ * busy; takes no lock, so a watchdog thread may call it while another thread waits in x265amd_sync */
+int  x265amd_debug_state(x265amd_ctx *ctx, char *buf, size_t n);
+/* GPU-side ordering against other streams (a collective's, a copy's) without a host wait: work queued
+ * on the context after x265amd_wait_event starts only when `event` (a hipEvent_t recorded on the other
+ * stream) has completed; x265amd_record_event records `event` behind everything queued on the context
+ * so far.  The reference's counterpart is the row-count hand-over between the frame that reconstructs a
+ * reference and the frames that search it (m_reconRowCount, encoder/framefilter.cpp:257,
+ * encoder/frameencoder.cpp:906-918). */
+int  x265amd_wait_event(x265amd_ctx *ctx, void *event);
+int  x265amd_record_event(x265amd_ctx *ctx, void *event);
 
 /* ---- planes --------------------------------------------------------------------------
  * A plane is a border-extended luma picture as TComPicYuv lays it out
@@ -98,6 +109,10 @@ int x265amd_plane_create(x265amd_ctx *ctx, int width, int height, int margin_x, 
                          int bytes_per_px, int bit_depth, int *plane_id);
 int x265amd_plane_update_rows(x265amd_ctx *ctx, int plane_id, const void *host_origin, intptr_t host_stride,
                               int y0, int n_rows);
+/* geometry a plane was registered with (TComPicYuv::getWidth / getHeight / getLumaMarginX / getStride,
+ * Lib/TLibCommon/TComPicYuv.h); any pointer may be NULL */
+int x265amd_plane_geometry(x265amd_ctx *ctx, int plane_id, int *width, int *height, int *margin_x, int *margin_y,
+                           intptr_t *stride, int *bytes_per_px, int *bit_depth);
 /* device address of the padded allocation of a plane (upload target / broadcast buffer) */
 void *x265amd_plane_device_ptr(x265amd_ctx *ctx, int plane_id);
 int x265amd_plane_release(x265amd_ctx *ctx, int plane_id);
@@ -125,6 +140,20 @@ int x265amd_lowres_update(x265amd_ctx *ctx, int lowres_plane, int src_plane);
  * (common/lowres.cpp:35-46, encoder/slicetype.cpp:74-75); any pointer may be NULL */
 int x265amd_lowres_geometry(x265amd_ctx *ctx, int lowres_plane, int *width, int *lines, intptr_t *stride,
                             int *cu_w, int *cu_h);
+
+/* ---- 8-tap luma interpolation ------------------------------------------------------------
+ * One call of EncoderPrimitives::ipfilter_pp[FILTER_H_P_P_8] (kind 0), ipfilter_pp[FILTER_V_P_P_8]
+ * (kind 1), ipfilter_ps[FILTER_H_P_S_8] (kind 2: pixel -> short) or ipfilter_sp[FILTER_V_S_P_8]
+ * (kind 3: short -> pixel) (common/primitives.h:186-188, 263-265; bodies common/ipfilter.cpp:91-139,
+ * 354-425, 265-309, 38-89) with the taps g_lumaFilter[frac] (Lib/TLibCommon/TComRom.cpp:176-182) on HOST
+ * pointers: src / dst address element (0,0) of the block, strides in elements, and the source must be
+ * readable 3 elements before and 4 behind the block in the filtered direction, as in the reference.
+ * `bit_depth` plays the role of X265_DEPTH (headRoom = 14 - bit_depth).  The block is staged to the GPU
+ * and filtered by the device functions the motion search interpolates with (subpelCompare's H, V and
+ * H-then-V chains), so this entry point is how those are checked against the reference's filters one to
+ * one; it is not a performance path. */
+int x265amd_ipfilter(x265amd_ctx *ctx, int kind, const void *src, intptr_t src_stride, void *dst, intptr_t dst_stride,
+                     int w, int h, int frac, int bytes_per_px, int bit_depth);
 
 /* ---- batched block costs -------------------------------------------------------------
  * n independent evaluations of EncoderPrimitives::sad / satd / sa8d_inter
@@ -169,8 +198,10 @@ typedef struct x265amd_me_result
 } x265amd_me_result;
 
 /* jobs / out in host memory; blocks until the results are in `out`.  X265AMD_ERR_RANGE if a job's
- * bounds (+3 pixels of pattern overshoot, +3/+4 of filter apron) leave the reference plane's margins;
- * the device-array and job-list forms below do not check (the kernels clamp addresses) */
+ * bounds (+3 pixels of pattern overshoot, +3/+4 of filter apron) leave the reference plane's margins.
+ * Job lists are checked the same way when they run (once per plane geometry); only the device-array
+ * form cannot check (its jobs are not visible to the host; the kernels clamp addresses, so a violation
+ * measures other pixels than the reference would, it does not fault). */
 int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                             const x265amd_me_job *jobs, int n, x265amd_me_result *out);
 
@@ -187,10 +218,14 @@ int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *r
 typedef struct x265amd_joblist x265amd_joblist;
 int x265amd_joblist_create(x265amd_ctx *ctx, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,
                            x265amd_joblist **out);
-/* run the list against planes; out == NULL: asynchronous, results stay in device memory */
+/* run the list against planes; out == NULL: asynchronous, results stay in device memory.
+ * X265AMD_ERR_INVALID if n_refs is smaller than the n_refs the list was created with,
+ * X265AMD_ERR_RANGE as for x265amd_me_search_batch */
 int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
                         x265amd_me_result *out);
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
+/* wait for the list's last run and copy its results (list length entries) to `out` in host memory */
+int x265amd_joblist_results(x265amd_ctx *ctx, x265amd_joblist *list, x265amd_me_result *out);
 /* Reorder the list's launches so that the jobs that took the most block-cost evaluations in its last
  * run start first (results do not depend on the order; a launch ends with its longest searches, and
  * consecutive frames move alike).  Blocks until the last run has finished.  No counterpart in the
@@ -210,7 +245,13 @@ int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
  * out == NULL: asynchronous, results stay in device memory (x265amd_lookahead_results_device). */
 int x265amd_lookahead_me(x265amd_ctx *ctx, int n_pairs, const int *enc_lowres, const int *ref_lowres,
                          int merange, int method, int subme, int qp, x265amd_me_result *out);
+/* The device array holding the last call's fields.  The pointer stays valid until the next
+ * x265amd_lookahead_me call on the context (which may re-allocate it) or x265amd_destroy. */
 const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *ctx);
+/* Waits for the lookahead searches queued so far and reports whether the last call completed: 0, or
+ * X265AMD_ERR_HIP if a CU row gave up waiting for the row below it (its field is then not valid).
+ * The synchronous form of x265amd_lookahead_me (out != NULL) performs this check itself. */
+int x265amd_lookahead_status(x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last
  * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */

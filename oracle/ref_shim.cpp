@@ -9,7 +9,9 @@
  * the CPU restatement in oracle/me_oracle.c can be validated against the real
  * reference and golden vectors can be generated from it.
  *
- * Built twice: -DHIGH_BIT_DEPTH=0 (pixel = uint8_t) and =1 (pixel = uint16_t).
+ * Built three times: -DHIGH_BIT_DEPTH=0 (pixel = uint8_t) and =1 (pixel = uint16_t) with the C
+ * primitives only, and -DHIGH_BIT_DEPTH=0 -DREF_WITH_VEC=1 with the reference's intrinsic primitives
+ * dispatched over them (the CPU-baseline build).
  */
 #include "primitives.h"
 #include "common.h"
@@ -43,6 +45,7 @@ bool g_init = false;
 extern "C" {
 
 int ref_pixel_bytes(void) { return (int)sizeof(pixel); }
+int ref_with_vec(void) { return REF_WITH_VEC; }
 
 int ref_init(void)
 {
@@ -51,8 +54,14 @@ int ref_init(void)
         x265_param_t param;
         memset(&param, 0, sizeof(param));
         param.logLevel = X265_LOG_NONE;
+#if REF_WITH_VEC
+        /* cpuid = 0: detect the CPU and layer the intrinsic primitives over the C ones, as the encoder
+         * does (primitives.cpp:107-139) */
+        x265_setup_primitives(&param, 0);
+#else
         /* cpuid = 1: C primitives only (primitives.cpp:129-139 loops from 2) */
         x265_setup_primitives(&param, 1);
+#endif
         g_init = true;
     }
     return 0;

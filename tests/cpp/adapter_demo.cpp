@@ -56,6 +56,22 @@ int main(int argc, char **argv)
             int cost = me.motionEstimate(&pr, x265amd::MV(-16, -16), x265amd::MV(16, 16), x265amd::MV(5, -3), 2, mvc, 16, out);
             printf("single %d %d %d %d\n", method, out.x, out.y, cost);
         }
+        // (1b) linear PU offsets (the reference's setSourcePU argument) all over the padded plane: right half,
+        //      flush with the right edge, inside the left / right / top margins; each against the (x, y) form
+        {
+            me.setSearchMethod(1);
+            me.setSubpelRefine(2);
+            const int px[6] = { W - 48, W - 16, -8, W + 8 - 16, 160, 16 }, py[6] = { 40, 64, 24, 8, -8, H - 16 };
+            for (int k = 0; k < 6; k++)
+            {
+                x265amd::MV a, b;
+                me.setSourcePU(py[k] * stride + px[k], 16, 16);
+                int ca = me.motionEstimate(&pr, x265amd::MV(-8, -8), x265amd::MV(8, 8), x265amd::MV(2, 1), 0, NULL, 8, a);
+                me.setSourcePUxy(px[k], py[k], 16, 16);
+                int cb = me.motionEstimate(&pr, x265amd::MV(-8, -8), x265amd::MV(8, 8), x265amd::MV(2, 1), 0, NULL, 8, b);
+                printf("srcpu %d %d %d %d %d %d %d %d\n", px[k], py[k], a.x, a.y, ca, b.x, b.y, cb);
+            }
+        }
         // (2) batched: one row of 16x16 PUs queued, then flushed
         me.setSearchMethod(1);
         me.setSubpelRefine(2);

@@ -17,7 +17,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libme_oracle.so")
 REF_SO = {8: os.path.join(ROOT, "oracle", "_ref", "libx265ref8.so"),
-          16: os.path.join(ROOT, "oracle", "_ref", "libx265ref16.so")}
+          16: os.path.join(ROOT, "oracle", "_ref", "libx265ref16.so"),
+          # 8-bit pixels with the reference's intrinsic (SSE3 .. SSE4.1) primitives dispatched over the C ones
+          "8v": os.path.join(ROOT, "oracle", "_ref", "libx265ref8v.so")}
 
 import sys
 sys.path.insert(0, ROOT)
@@ -140,16 +142,19 @@ class Oracle:
 
 
 class Reference:
-    """The compiled reference (C primitives only, cpuid=1)."""
+    """The compiled reference: C primitives only (cpuid=1) for bits 8 / 16; "8v" = 8-bit pixels with the
+    reference's intrinsic primitives selected by its own run-time dispatch (the CPU-baseline build)."""
 
-    def __init__(self, bits: int = 8):
+    def __init__(self, bits=8):
         so = REF_SO[bits]
         if not os.path.exists(so):
             raise FileNotFoundError(so)
         L = self.lib = C.CDLL(so)
+        self.vec = bits == "8v"
+        bits = 8 if self.vec else bits
         self.bits = bits
         L.ref_init()
-        assert L.ref_pixel_bytes() == bits // 8
+        assert L.ref_pixel_bytes() == bits // 8 and bool(L.ref_with_vec()) == self.vec
         L.ref_cmp.restype = C.c_int
         L.ref_cmp.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
         L.ref_sad_x3.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_ssize_t, C.c_void_p]
@@ -275,5 +280,5 @@ class Reference:
         return out
 
 
-def have_reference(bits: int = 8) -> bool:
+def have_reference(bits=8) -> bool:
     return os.path.exists(REF_SO[bits])

@@ -37,6 +37,16 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
         jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -16, -16, 16, 16
         exp, _ = oracle.search(fr[0], [fr[1]], jb)
         assert (int(l[2]), int(l[3]), int(l[4])) == (int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])), l
+    # (1b) linear offsets anywhere in the padded plane map to the same PU as explicit coordinates
+    rows = [l for l in lines if l[0] == "srcpu"]
+    assert len(rows) == 6
+    for l in rows:
+        x, y = int(l[1]), int(l[2])
+        assert l[3:6] == l[6:9], l
+        jb = J.make_jobs(W, H, [x], [y], 16, 16, method=J.HEX, subme=2, merange=8, qp=30, qmvp=(2, 1))
+        jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = -8, -8, 8, 8
+        exp, _ = oracle.search(fr[0], [fr[1]], jb)
+        assert (int(l[3]), int(l[4]), int(l[5])) == (int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])), l
     # (2) batch
     xs = np.arange(0, W - 15, 16)
     jb = J.make_jobs(W, H, xs, np.full_like(xs, 16), 16, 16, method=J.HEX, subme=2, merange=24, qp=30)

@@ -82,3 +82,86 @@ def test_4k_10bit_all_pu_shapes_sa8d(eng, oracle):
     assert eng.eval_count() == evals
     for i in ids:
         eng.release_plane(i)
+
+
+def _single_rank_group():
+    """a process group of ONE rank on this GPU, so that the collective of the multi-GPU path really runs
+    (RCCL when it initialises, else gloo); returns the backend name"""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_backend()
+    import os
+    port = 29700 + (os.getpid() % 200)
+    last = None
+    for backend in ("nccl", "gloo"):
+        try:
+            kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+            dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+            return backend
+        except Exception as e:      # pragma: no cover - depends on the box
+            last = e
+            port += 1
+    raise last
+
+
+def test_4k_lookahead_batch_through_plane_ring(oracle):
+    """BASELINE's 4K 8-frame lookahead batch on the rank that would own all of it: the frames of the
+    batch are searched one after the other, each against the reference plane that arrives through
+    PlaneRing (broadcast into one of two device buffers wrapped with x265amd_plane_wrap_device, the
+    next plane's broadcast queued beside the current frame's searches, all hand-overs stream events).
+    Results of every frame are compared with the oracle on a sample of PUs (all methods + FULL)."""
+    import torch
+    import torch.distributed as dist
+    from x265_amd import dist as xd
+    from x265_amd.api import Engine
+    backend = _single_rank_group()
+    dev = torch.device("cuda", 0)
+    eng = Engine(0)
+    NF = 8
+    rng = np.random.default_rng(31)
+    fr = synth.make_sequence(W4K, H4K, NF + 2, seed=99)          # frames 0, 1: the two references; 2..9: the batch
+    stride = fr[0].shape[1]
+    parts = []
+    for method, subme, n in ((J.HEX, 5, 40), (J.STAR, 2, 12), (J.UMH, 3, 12), (J.DIA, 7, 12)):
+        for (w, h) in ((64, 64), (16, 16), (8, 8)):
+            parts.append(_sampled(W4K, H4K, w, h, n // 2, rng, method=method, subme=subme, merange=64, qp=32,
+                                  qmvp=(int(rng.integers(-40, 40)), int(rng.integers(-40, 40)))))
+    for (w, h, n) in ((64, 64, 2), (32, 32, 3), (16, 16, 6), (8, 8, 10)):
+        parts.append(_sampled(W4K, H4K, w, h, n, rng, method=J.FULL, subme=0, merange=64, qp=32))
+    jobs = np.concatenate(parts)
+    jls = [eng.make_joblist(jobs) for _ in range(NF)]          # one list (and result buffer) per frame of the batch
+    # the owner's copies of the reference planes (host side) and the two-buffer ring on the device
+    host_refs = [torch.from_numpy(fr[0]).pin_memory(), torch.from_numpy(fr[1]).pin_memory()]
+    bufs = [torch.zeros(fr[0].shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+    buf_ids = [eng.wrap_device_plane(b.data_ptr(), W4K, H4K, stride, 1, 8) for b in bufs]
+    encs = [torch.from_numpy(f).to(dev) for f in fr[2:]]
+    enc_ids = [eng.wrap_device_plane(t.data_ptr(), W4K, H4K, stride, 1, 8) for t in encs]
+    ring = xd.PlaneRing(bufs, engine=eng, src=0, overlap=True)
+    cur = torch.cuda.current_stream(dev)
+
+    def publish(k):
+        # the owner writes reference k (the frames alternate between the two references) into the ring
+        # buffer it is about to broadcast, once the searches still reading that buffer are done
+        b = ring.slot(k)
+        if ring.free[b] is not None:
+            cur.wait_event(ring.free[b])
+        bufs[b].copy_(host_refs[k & 1], non_blocking=True)
+
+    publish(0)
+    for k in range(NF):                     # nothing in this loop waits on the host
+        b = ring.acquire(k)
+        assert b == (k & 1)
+        jls[k].run(enc_ids[k], [buf_ids[b]], fetch=False)
+        if k + 1 < NF:
+            publish(k + 1)
+            ring.prefetch(k + 1)
+        ring.release(k)
+    eng.sync()
+    for k in range(NF):
+        got = jls[k].results()
+        exp, _ = oracle.search(fr[2 + k], [fr[k & 1]], jobs, threads=8)
+        assert np.array_equal(got, exp), (backend, k, np.nonzero(got != exp)[0][:5])
+        jls[k].close()
+    eng.close()
+    dist.destroy_process_group()

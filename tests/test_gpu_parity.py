@@ -269,6 +269,75 @@ def test_device_resident_and_planned_paths_agree(eng, oracle):
         eng.release_plane(i)
 
 
+class GpuIp:
+    """the stand-alone 8-tap filter entry point (x265amd_ipfilter) behind golden_cases.run_ip_suite"""
+
+    def __init__(self, eng, bits):
+        self.eng, self.bpp = eng, bits // 8
+
+    def ipfilter_run(self, kind, src, x0, y0, w, h, frac, depth):
+        return self.eng.ipfilter(kind, np.ascontiguousarray(src), x0, y0, w, h, frac, depth, self.bpp)
+
+
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 8), (16, 10)])
+def test_interpolation_matches_reference_vectors(eng, bits, depth):
+    """ipfilter_pp[H_8] / ipfilter_pp[V_8] / ipfilter_ps[H_8] / ipfilter_sp[V_8] of the compiled reference
+    (3 phases x 7 block sizes each, incl. the (w+1) x h and w x (h+1) blocks of the half-pel pairs), replayed
+    through the device functions the search interpolates with.  Depth 10 includes the reference's
+    cast-to-short-before-the-shift wrap-around (common/ipfilter.cpp:129,302)."""
+    gold = _load("ipfilter_u%d_d%d.npz" % (bits, depth))
+    got = G.run_ip_suite(GpuIp(eng, bits), bits, depth)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert gold[k].dtype == got[k].dtype and np.array_equal(gold[k], got[k]), k
+
+
+def test_interpolation_hv_chain_matches_oracle(eng, oracle):
+    """ps-H over rows -3 .. h+4 into a `short` intermediate, then sp-V: subpelCompare's diagonal case
+    (encoder/motion.cpp:1158-1161), on the GPU entry point against the CPU restatement, 8- and 10-bit"""
+    for bits, depth in ((8, 8), (16, 10)):
+        src, _ = G.ip_source(bits)
+        bpp = bits // 8
+        for (w, h, xf, yf) in ((16, 16, 1, 3), (64, 32, 2, 2), (8, 8, 3, 1), (12, 16, 1, 1)):
+            tmp = eng.ipfilter(2, src, 20, 20 - 3, w, h + 7, xf, depth, bpp)
+            got = eng.ipfilter(3, tmp, 0, 3, w, h, yf, depth, bpp)
+            etmp = np.zeros((h + 7, w), np.int16)
+            oracle.ipfilter(2, src, (20 - 3) * src.shape[1] + 20, src.shape[1], etmp, 0, w, w, h + 7, xf, depth, bpp)
+            exp = np.zeros((h, w), src.dtype)
+            oracle.ipfilter(3, etmp, 3 * w, w, exp, 0, w, w, h, yf, depth, bpp)
+            assert np.array_equal(tmp, etmp) and np.array_equal(got, exp), (bits, w, h, xf, yf)
+
+
+def test_joblist_reference_count_and_ranges_are_checked(eng):
+    """a list made for two references does not run with one; a list whose windows leave the planes' margins is refused"""
+    from x265_amd.api import X265AmdError
+    fr = synth.make_sequence(128, 128, 3, seed=5)
+    ids = [eng.upload_plane(f) for f in fr]
+    jobs = J.make_jobs(128, 128, [16, 32], [16, 32], 16, 16, method=J.HEX, subme=1, merange=8, qp=30)
+    jobs["ref_idx"] = [0, 1]
+    jl = eng.make_joblist(jobs, n_refs=2)
+    jl.run(ids[0], [ids[1], ids[2]])
+    with pytest.raises(X265AmdError, match="-2"):
+        jl.run(ids[0], [ids[1]])
+    jl.close()
+    bad = jobs.copy()
+    bad["ref_idx"] = 0
+    bad["mvmin_x"] = -100
+    jl = eng.make_joblist(bad)
+    with pytest.raises(X265AmdError, match="-5"):
+        jl.run(ids[0], [ids[1]])
+    jl.close()
+    for i in ids:
+        eng.release_plane(i)
+
+
+def test_plane_geometry_query(eng):
+    fr = synth.make_sequence(96, 64, 1, seed=2)
+    pid = eng.upload_plane(fr[0])
+    assert eng.plane_geometry(pid) == (96, 64, synth.MARGIN, synth.MARGIN, 96 + 2 * synth.MARGIN, 1, 8)
+    eng.release_plane(pid)
+
+
 def test_errors_are_reported(eng):
     fr = synth.make_sequence(64, 64, 2, seed=1)
     ids = [eng.upload_plane(f) for f in fr]

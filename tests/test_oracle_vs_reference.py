@@ -37,3 +37,29 @@ def test_random_jobs(oracle, bits, depth):
         b = ref.search(fr[0], [fr[1]], jobs)
         bad = np.nonzero(a != b)[0]
         assert bad.size == 0, (jobs[bad[:2]], a[bad[:2]], b[bad[:2]])
+
+
+@pytest.mark.skipif(not have_reference("8v"), reason="vector build of oracle/_ref absent")
+def test_vector_primitive_build_equals_c_build(oracle):
+    """the reference's intrinsic primitives (its own differential-test property, test/testbench.cpp:107-134):
+    searches through the SSE4.1-dispatched build return what the C build and the restatement return"""
+    ref = Reference("8v")
+    W, H = 352, 288
+    rng = np.random.default_rng(77)
+    fr = synth.make_sequence(W, H, 2, seed=9)
+    parts = []
+    for _ in range(120):
+        w, h = int(rng.choice(J.DIMS)), int(rng.choice(J.DIMS))
+        method = int(rng.integers(0, 5))
+        if method == J.UMH and w == 4 and h == 4:
+            continue
+        px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+        py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        parts.append(J.make_jobs(W, H, [px], [py], w, h, method=method, subme=int(rng.integers(0, 8)),
+                                 merange=int(rng.integers(4, 20)) if method == J.FULL else int(rng.integers(4, 70)),
+                                 qp=int(rng.integers(0, 52)), qmvp=(int(rng.integers(-100, 100)), int(rng.integers(-100, 100)))))
+    jobs = np.concatenate(parts)
+    a, _ = oracle.search(fr[0], [fr[1]], jobs, threads=2)
+    b = ref.search(fr[0], [fr[1]], jobs)
+    bad = np.nonzero(a != b)[0]
+    assert bad.size == 0, (jobs[bad[:2]], a[bad[:2]], b[bad[:2]])

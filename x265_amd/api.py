@@ -67,6 +67,12 @@ def load_library() -> C.CDLL:
     plane_args = [vp, vp, ci, ci, ci, ci, C.c_ssize_t, ci, ci, cip]
     L.x265amd_plane_upload.argtypes = plane_args
     L.x265amd_plane_wrap_device.argtypes = plane_args
+    L.x265amd_debug_state.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.x265amd_wait_event.argtypes = [vp, vp]
+    L.x265amd_record_event.argtypes = [vp, vp]
+    L.x265amd_plane_geometry.argtypes = [vp, ci, cip, cip, cip, cip, C.POINTER(C.c_ssize_t), cip, cip]
+    L.x265amd_ipfilter.argtypes = [vp, ci, vp, C.c_ssize_t, vp, C.c_ssize_t, ci, ci, ci, ci, ci]
+    L.x265amd_lookahead_status.argtypes = [vp]
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
     L.x265amd_plane_device_ptr.restype = vp
     L.x265amd_plane_release.argtypes = [vp, ci]
@@ -86,6 +92,7 @@ def load_library() -> C.CDLL:
     L.x265amd_joblist_run.argtypes = [vp, vp, ci, cip, ci, vp]
     L.x265amd_joblist_results_device.argtypes = [vp]
     L.x265amd_joblist_results_device.restype = vp
+    L.x265amd_joblist_results.argtypes = [vp, vp, vp]
     L.x265amd_joblist_destroy.argtypes = [vp, vp]
     L.x265amd_joblist_rebalance.argtypes = [vp, vp]
     L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
@@ -139,6 +146,43 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.x265amd_sync(self.h))
+
+    def debug_state(self) -> str:
+        buf = C.create_string_buffer(512)
+        self.lib.x265amd_debug_state(self.h, buf, 512)
+        return buf.value.decode()
+
+    def wait_event(self, event):
+        """work queued on the engine from now on starts after `event` (a torch.cuda.Event recorded on another stream)"""
+        self._chk(self.lib.x265amd_wait_event(self.h, event.cuda_event))
+
+    def record_event(self, event):
+        """record `event` (a torch.cuda.Event) behind everything queued on the engine so far"""
+        event.record(self.torch_stream())
+
+    def plane_geometry(self, pid: int):
+        """(width, height, margin_x, margin_y, stride, bytes_per_px, bit_depth)"""
+        v = [C.c_int() for _ in range(6)]
+        st = C.c_ssize_t()
+        self._chk(self.lib.x265amd_plane_geometry(self.h, pid, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]),
+                                                  C.byref(st), C.byref(v[4]), C.byref(v[5])))
+        return v[0].value, v[1].value, v[2].value, v[3].value, st.value, v[4].value, v[5].value
+
+    def ipfilter(self, kind: int, src: np.ndarray, x0: int, y0: int, w: int, h: int, frac: int, depth: int,
+                 bytes_per_px: int) -> np.ndarray:
+        """one 8-tap luma filter call (kind 0 pp-H, 1 pp-V, 2 ps-H, 3 sp-V) on the w x h block at (x0, y0) of the
+        2-D array `src` (pixels; int16 for kind 3); pixels are `bytes_per_px` wide"""
+        assert src.flags["C_CONTIGUOUS"] and src.ndim == 2
+        pix = np.uint8 if bytes_per_px == 1 else np.uint16
+        assert src.dtype == (np.int16 if kind == 3 else pix)
+        dst = np.zeros((h, w), dtype=np.int16 if kind == 2 else pix)
+        ss = src.shape[1]
+        self._chk(self.lib.x265amd_ipfilter(self.h, kind, src.ctypes.data + (y0 * ss + x0) * src.itemsize, ss,
+                                            dst.ctypes.data, w, w, h, frac, bytes_per_px, depth))
+        return dst
+
+    def lookahead_status(self):
+        self._chk(self.lib.x265amd_lookahead_status(self.h))
 
     # -- planes ------------------------------------------------------------------------------
     def upload_plane(self, padded: np.ndarray, bit_depth=None, margin: int = MARGIN) -> int:
@@ -277,6 +321,12 @@ class JobList:
         out = np.zeros(self.n, dtype=RESULT_DTYPE) if fetch else None
         self.eng._chk(self.eng.lib.x265amd_joblist_run(self.eng.h, self.h, enc_plane, refs, len(ref_planes),
                                                        out.ctypes.data if fetch else None))
+        return out
+
+    def results(self) -> np.ndarray:
+        """the results of the list's last run (waits for it): for runs queued with fetch=False"""
+        out = np.zeros(self.n, dtype=RESULT_DTYPE)
+        self.eng._chk(self.eng.lib.x265amd_joblist_results(self.eng.h, self.h, out.ctypes.data))
         return out
 
     def rebalance(self):

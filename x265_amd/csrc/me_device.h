@@ -564,6 +564,54 @@ struct Dev
         return v > maxval ? maxval : v;
     }
 
+    // ---- the reference's four luma filter primitives on one group of 4 outputs (common/ipfilter.cpp
+    // with hr = headRoom = 14 - depth); the search's prediction code and the stand-alone filter
+    // kernel (k_ipfilter) both go through these.
+    // ipfilter_pp[H_8] = filterHorizontal_p_p (ipfilter.cpp:91-139): 12 packed pixels -> 4 pixels
+    static __device__ __forceinline__ void h_pp(const uint32_t *px, int xf, int depth, int *out)
+    {
+        const int hr = 14 - depth, maxval = (1 << depth) - 1;
+        int sum[4];
+        filt8x4(px, xf, 1 << (hr - 1), sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = clamp_pix(as_short(as_short(sum[i]) >> hr), maxval);      // cast to short before the shift (:129)
+    }
+    // ipfilter_pp[V_8] = filterVertical_p_p (ipfilter.cpp:354-425): 8 rows of 4 packed pixels -> 4 pixels
+    static __device__ __forceinline__ void v_pp(const uint32_t (*rw)[2], int yf, int depth, int *out)
+    {
+        const int maxval = (1 << depth) - 1;
+        int sum[4];
+        vfilt8x4(rw, yf, 32, sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = clamp_pix(as_short(sum[i] >> 6), maxval);
+    }
+    // ipfilter_ps[H_8] = filterHorizontal_p_s (ipfilter.cpp:265-309): 12 packed pixels -> 4 `short` values
+    static __device__ __forceinline__ void h_ps(const uint32_t *px, int xf, int depth, int *out)
+    {
+        const int hr = 14 - depth, sh2 = 6 - hr;
+        int sm[4];
+        filt8x4(px, xf, -8192 * (1 << sh2), sm);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = as_short(as_short(sm[i]) >> sh2);                          // cast before the shift (:302)
+    }
+    // ipfilter_sp[V_8] = filterVertical_s_p (ipfilter.cpp:38-89): 8 rows of 4 packed `short` values -> 4 pixels
+    static __device__ __forceinline__ void v_sp(const uint32_t (*rw)[2], int yf, int depth, int *out)
+    {
+        const int hr = 14 - depth, maxval = (1 << depth) - 1;
+        const int sh3 = 6 + hr, off3 = (1 << (sh3 - 1)) + (8192 << 6);
+        const Taps16 ty(yf);
+        int sum[4] = { off3, off3, off3, off3 };
+#pragma unroll
+        for (int k = 0; k < 8; k += 2)
+            vpair16(rw[k], rw[k + 1], ty.p[k / 2], sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = clamp_pix(as_short(sum[i] >> sh3), maxval);
+    }
+
     // ------------------------------------------------------------------ Hadamard partials
     // d = fenc - pred of this lane's 4 pixels.  The row transform is done inside the lane; the column
     // transform runs across lanes, each stage as t = +-t + partner(t) with the sign a per-lane
@@ -820,18 +868,12 @@ struct Dev
             return unpack4(d);
         }
         const int depth = DW == 1 ? 8 : depth_rt;     // 8-bit planes: every shift and bound is a constant
-        const int hr = 14 - depth;
-        const int maxval = (1 << depth) - 1;
         P4 r;
         if (mode == PRED_H)        // filterHorizontal_p_p, ipfilter.cpp:91-139
         {
             uint32_t px[6];
             src.template rd12_packed<LW>(off - 3 * step, px);
-            int sum[4];
-            filt8x4(px, xf, 1 << (hr - 1), sum);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                r.v[i] = clamp_pix(as_short(as_short(sum[i]) >> hr), maxval);
+            h_pp(px, xf, depth, r.v);
             return r;
         }
         if (mode == PRED_V)        // filterVertical_p_p, ipfilter.cpp:354-425
@@ -840,32 +882,22 @@ struct Dev
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 src.template rd4_packed<LW>(off + (k - 3) * pitch, rw[k]);
-            int sum[4];
-            vfilt8x4(rw, yf, 32, sum);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                r.v[i] = clamp_pix(as_short(sum[i] >> 6), maxval);
+            v_pp(rw, yf, depth, r.v);
             return r;
         }
         // PRED_HV, second half: filterVertical_s_p (ipfilter.cpp:38-89) over the LDS intermediate,
         // whose row k holds picture row (k - 3) of the candidate block
         {
-            const int sh3 = 6 + hr;
-            const int off3 = (1 << (sh3 - 1)) + (8192 << 6);
             const XA_LDS int16_t *m = v.l->imm + ioff;
-            const Taps16 ty(yf);
-            int sum[4] = { off3, off3, off3, off3 };
+            uint32_t rw[8][2];
 #pragma unroll
-            for (int k = 0; k < 8; k += 2)
+            for (int k = 0; k < 8; k++)
             {
-                const uint64_t d0 = *(const XA_LDS uint64_t*)(m + k * w);
-                const uint64_t d1 = *(const XA_LDS uint64_t*)(m + (k + 1) * w);
-                const uint32_t a[2] = { (uint32_t)d0, (uint32_t)(d0 >> 32) }, b[2] = { (uint32_t)d1, (uint32_t)(d1 >> 32) };
-                vpair16(a, b, ty.p[k / 2], sum);
+                const uint64_t d = *(const XA_LDS uint64_t*)(m + k * w);
+                rw[k][0] = (uint32_t)d;
+                rw[k][1] = (uint32_t)(d >> 32);
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                r.v[i] = clamp_pix(as_short(sum[i] >> sh3), maxval);
+            v_sp(rw, yf, depth, r.v);
             return r;
         }
     }
@@ -880,9 +912,6 @@ struct Dev
     {
         constexpr int step = LW ? PB : 1;
         const int depth = DW == 1 ? 8 : depth_rt;
-        const int hr = 14 - depth;
-        const int sh2 = 6 - hr;
-        const int off2 = -8192 * (1 << sh2);
         const int ngx = w >> 2;
         const int n = (h + 8) * ngx;
         for (int idx = v.tid; idx < n; idx += NT)
@@ -891,10 +920,7 @@ struct Dev
             uint32_t px[6];
             src.template rd12_packed<LW>(off + (row - 3) * pitch + (col - 3) * step, px);
             int sm[4];
-            filt8x4(px, xf, off2, sm);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                sm[i] = as_short(as_short(sm[i]) >> sh2);
+            h_ps(px, xf, depth, sm);
             const uint32_t lo = __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100), hi = __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100);
             *(XA_LDS uint64_t*)(v.l->imm + row * w + col) = (uint64_t)lo | ((uint64_t)hi << 32);
         }

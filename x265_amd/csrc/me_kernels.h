@@ -97,4 +97,64 @@ __global__ void __launch_bounds__(64) k_cost(const PlaneDesc *planes, int kind, 
         out[id] = c;
 }
 
+// ------------------------------------------------------------------------------------------
+// The four 8-tap luma filter primitives on their own (common/primitives.h:186-188, 263-265;
+// common/ipfilter.cpp:38-139, 265-309, 354-425), through the same device functions the search's
+// prediction code uses.  kind 0 = ipfilter_pp[H_8], 1 = ipfilter_pp[V_8], 2 = ipfilter_ps[H_8]
+// (pixel -> short), 3 = ipfilter_sp[V_8] (short -> pixel).  `src` addresses element (0,0) of the block
+// inside a staged copy that holds 3 rows / columns before and 4 (+3 of load slack) behind it; one
+// thread produces 4 adjacent outputs; `dst` is a dense w x h array.
+template <typename PIX>
+__global__ void __launch_bounds__(256) k_ipfilter(int kind, const void *src, int sstride, void *dst, int w, int h, int frac, int depth)
+{
+    typedef Dev<JobLds<PIX, 1, 64>> D;
+    const int ngx = (w + 3) >> 2;
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (t >= ngx * h)
+        return;
+    const int y = t / ngx, x = (t - y * ngx) * 4;
+    int out[4];
+    if (kind == 0 || kind == 2)
+    {
+        const PIX *p = (const PIX*)src + (int64_t)y * sstride + x - 3;
+        uint32_t px[6];
+#pragma unroll
+        for (int i = 0; i < 3 * D::DW; i++)
+            px[i] = ld_u32((const uint8_t*)p + 4 * i);
+        if (kind == 0) D::h_pp(px, frac, depth, out);
+        else           D::h_ps(px, frac, depth, out);
+    }
+    else if (kind == 1)
+    {
+        uint32_t rw[8][2];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const PIX *p = (const PIX*)src + (int64_t)(y + k - 3) * sstride + x;
+            rw[k][0] = ld_u32(p);
+            rw[k][1] = D::DW == 2 ? ld_u32((const uint8_t*)p + 4) : 0;
+        }
+        D::v_pp(rw, frac, depth, out);
+    }
+    else
+    {
+        uint32_t rw[8][2];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const uint64_t d = ld_u64((const int16_t*)src + (int64_t)(y + k - 3) * sstride + x);
+            rw[k][0] = (uint32_t)d;
+            rw[k][1] = (uint32_t)(d >> 32);
+        }
+        D::v_sp(rw, frac, depth, out);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (x + i < w)
+        {
+            if (kind == 2) ((int16_t*)dst)[(int64_t)y * w + x + i] = (int16_t)out[i];
+            else           ((PIX*)dst)[(int64_t)y * w + x + i] = (PIX)out[i];
+        }
+}
+
 } // namespace xa

@@ -74,10 +74,11 @@ struct x265amd_ctx
     // side on auxiliary streams, so that one launch's tail overlaps the others: fork() makes the
     // auxiliary streams wait for the main one, join() the reverse.
     static constexpr int N_AUX = 3;
+    int n_lanes = N_AUX + 1;               // streams in use: 1 .. N_AUX + 1 (X265AMD_LANES)
     hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
     x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
-    hipStream_t lane(int k) const { return (k % (N_AUX + 1)) == 0 ? stream : aux[(k % (N_AUX + 1)) - 1]; }
+    hipStream_t lane(int k) const { return (k % n_lanes) == 0 ? stream : aux[(k % n_lanes) - 1]; }
 };
 
 // A planned job list: the jobs live in device memory together with the work-item plan of the
@@ -85,6 +86,9 @@ struct x265amd_ctx
 struct x265amd_joblist
 {
     int     n = 0, bpp = 1;
+    int     n_refs = 0;                   // reference planes the jobs were validated against (ref_idx < n_refs)
+    std::vector<x265amd_me_job> h_jobs;   // host copy, for the range check against the planes of a run
+    std::vector<int64_t> checked_geom;    // geometry of the planes the ranges were last checked against
     DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
@@ -251,12 +255,7 @@ constexpr int FULL_LDS_MAX = 64 * 1024;
 int record_start(x265amd_ctx *c)
 {
     if (c->timing)
-    {
-        for (int i = 0; i < 3; i++)
-            if (!c->ev[i])
-                HIPCHK(c, hipEventCreate(&c->ev[i]));
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    }
     c->timed_full = false;
     return 0;
 }
@@ -264,13 +263,13 @@ int record_start(x265amd_ctx *c)
 int fork_streams(x265amd_ctx *c, int lanes)
 {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int i = 0; i < x265amd_ctx::N_AUX && i + 1 < lanes; i++)
+    for (int i = 0; i + 1 < c->n_lanes && i + 1 < lanes; i++)
         HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
     return 0;
 }
 int join_streams(x265amd_ctx *c, int lanes)
 {
-    for (int i = 0; i < x265amd_ctx::N_AUX && i + 1 < lanes; i++)
+    for (int i = 0; i + 1 < c->n_lanes && i + 1 < lanes; i++)
     {
         HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
@@ -314,7 +313,7 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
         }
     }
     // with index lists every launch has work: run the classes side by side
-    const int lanes = idx_base ? (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) : 1;
+    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0)) : 1;
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     bool lr = false;
@@ -340,27 +339,23 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
 }
 
 // Unplanned path (job array only in device memory): one exhaustive work item per job, built on the device.
+// Scratch of n jobs: one FullBest, one FullItem and one item-job index each.  Every slot a kernel of the
+// call reads is written earlier in the same call (k_make_items fills all items and indices; the exhaustive
+// kernel writes the FullBest of every job it is eligible for, and only those are read), so the buffers
+// need no clearing and may hold an earlier call's contents.
 int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
-                            x265amd_me_result *d_out)
+                            x265amd_me_result *d_out, FullBest *fb, FullItem *items, int *item_jobs)
 {
-    FullBest *fb = nullptr;
     if (int rc = record_start(c)) return rc;
-    {
-        if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
-        if (int rc = ensure(c, c->items, (size_t)n * sizeof(FullItem))) return rc;
-        if (int rc = ensure(c, c->item_jobs, (size_t)n * sizeof(int))) return rc;
-        fb = (FullBest*)c->fullbest.p;
-        hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n,
-                           (int*)c->item_jobs.p, (FullItem*)c->items.p);
-        if (bpp == 1)
-            hipLaunchKernelGGL((k_full_items<0, uint8_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
-                               (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
-        else
-            hipLaunchKernelGGL((k_full_items<0, uint16_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
-                               (const int*)c->item_jobs.p, (const FullItem*)c->items.p, n, fb, 1, FULL_LDS_MAX / 4);
-        HIPCHK(c, hipGetLastError());
-        c->timed_full = true;
-    }
+    hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n, item_jobs, items);
+    if (bpp == 1)
+        hipLaunchKernelGGL((k_full_items<0, uint8_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+                           (const int*)item_jobs, (const FullItem*)items, n, fb, 1, FULL_LDS_MAX / 4);
+    else
+        hipLaunchKernelGGL((k_full_items<0, uint16_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+                           (const int*)item_jobs, (const FullItem*)items, n, fb, 1, FULL_LDS_MAX / 4);
+    HIPCHK(c, hipGetLastError());
+    c->timed_full = true;
     return launch_general(c, P, bpp, d_jobs, n, nullptr, nullptr, fb, 1, d_out);
 }
 
@@ -636,7 +631,7 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 // the exhaustive-kernel launches of a planned list
 int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
-    const int lanes = (int)std::min<size_t>(L->launches.size(), x265amd_ctx::N_AUX + 1);
+    const int lanes = (int)std::min<size_t>(L->launches.size(), c->n_lanes);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     int k = 0;
@@ -724,6 +719,8 @@ int x265amd_create(int device, x265amd_ctx **out)
     memset(c->base, 0, sizeof(c->base));
     hipError_t e;
     e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 3 && e == hipSuccess; i++)
+        e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < x265amd_ctx::N_AUX && e == hipSuccess; i++)
     {
         e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
@@ -769,6 +766,9 @@ int x265amd_create(int device, x265amd_ctx **out)
         c->flags = atoi(ev);
         g_no_xcd_bands = (c->flags & 4) != 0;
     }
+    if (const char *ev = getenv("X265AMD_LANES"))        // streams the independent kernels of a batch are spread over
+        c->n_lanes = std::max(1, std::min(x265amd_ctx::N_AUX + 1, atoi(ev)));
+
     *out = c;
     return X265AMD_OK;
 }
@@ -821,6 +821,56 @@ int x265amd_sync(x265amd_ctx *c)
 }
 
 void *x265amd_stream(x265amd_ctx *c) { return c ? (void*)c->stream : nullptr; }
+
+int x265amd_debug_state(x265amd_ctx *c, char *buf, size_t n)
+{
+    if (!c || !buf || n == 0)
+        return X265AMD_ERR_INVALID;
+    // (no lock: meant to be called from a watchdog thread while another thread sits in x265amd_sync)
+    auto q = [](hipError_t e) { return e == hipSuccess ? "done" : e == hipErrorNotReady ? "BUSY" : hipGetErrorString(e); };
+    int at = snprintf(buf, n, "main stream %s", q(hipStreamQuery(c->stream)));
+    for (int i = 0; i < x265amd_ctx::N_AUX && at < (int)n; i++)
+        at += snprintf(buf + at, n - at, "; aux%d %s (join event %s)", i, q(hipStreamQuery(c->aux[i])), q(hipEventQuery(c->ev_join[i])));
+    if (at < (int)n)
+        at += snprintf(buf + at, n - at, "; fork event %s; lanes %d", q(hipEventQuery(c->ev_fork)), c->n_lanes);
+    return 0;
+}
+
+int x265amd_wait_event(x265amd_ctx *c, void *event)
+{
+    if (!c || !event)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
+int x265amd_record_event(x265amd_ctx *c, void *event)
+{
+    if (!c || !event)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord((hipEvent_t)event, c->stream));
+    return 0;
+}
+
+int x265amd_plane_geometry(x265amd_ctx *c, int id, int *width, int *height, int *margin_x, int *margin_y,
+                           intptr_t *stride, int *bytes_per_px, int *bit_depth)
+{
+    if (!c || id < 0 || id >= MAX_PLANES || !c->used[id])
+        return X265AMD_ERR_INVALID;
+    const PlaneDesc &d = c->h_planes[id];
+    if (width)        *width = d.width;
+    if (height)       *height = d.height;
+    if (margin_x)     *margin_x = d.margin_x;
+    if (margin_y)     *margin_y = d.margin_y;
+    if (stride)       *stride = d.stride;
+    if (bytes_per_px) *bytes_per_px = d.bpp;
+    if (bit_depth)    *bit_depth = d.depth;
+    return 0;
+}
 
 int x265amd_plane_upload(x265amd_ctx *c, const void *host_base, int width, int height, int margin_x, int margin_y,
                          intptr_t stride, int bpp, int depth, int *plane_id)
@@ -1011,7 +1061,17 @@ int x265amd_lowres_create(x265amd_ctx *c, int src_plane, int *lowres_plane)
     c->h_planes[id].lr_step = lg.elems;
     rc = lowres_fill(c, id, src_plane);
     if (rc)
+    {
+        // give the slot and the memory back
+        hipStreamSynchronize(c->stream);
+        hipFree(d);
+        c->used[id] = false;
+        c->owned[id] = nullptr;
+        c->base[id] = nullptr;
+        memset(&c->h_planes[id], 0, sizeof(PlaneDesc));
+        c->planes_dirty = true;
         return rc;
+    }
     *lowres_plane = id;
     return 0;
 }
@@ -1135,6 +1195,61 @@ int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, con
 const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
 {
     return c ? (const x265amd_me_result*)c->look_results.p : nullptr;
+}
+
+int x265amd_lookahead_status(x265amd_ctx *c)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->look_progress.p)
+        return 0;                       // no lookahead search was ever queued
+    int h_err = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_err, c->look_progress.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_err)
+        return fail(c, X265AMD_ERR_HIP, "lookahead search: a CU row waited too long for the row below it");
+    return 0;
+}
+
+int x265amd_ipfilter(x265amd_ctx *c, int kind, const void *src, intptr_t src_stride, void *dst, intptr_t dst_stride,
+                     int w, int h, int frac, int bpp, int depth)
+{
+    if (!c || !src || !dst)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (kind < 0 || kind > 3 || w <= 0 || h <= 0 || w > 4096 || h > 4096 || frac < 0 || frac > 3 ||
+        (bpp != 1 && bpp != 2) || depth < 8 || depth > 8 * bpp || depth > 14)
+        return fail(c, X265AMD_ERR_INVALID, "bad filter arguments");
+    // stage the block with the 8-tap apron (3 before, 4 behind) in the filtered direction only - the
+    // reference reads no more - plus zeroed slack for the 4-wide groups' loads
+    const bool horiz = kind == 0 || kind == 2;
+    const int se = kind == 3 ? 2 : bpp, de = kind == 2 ? 2 : bpp;          // bytes per source / output element
+    const int ax0 = horiz ? 3 : 0, ax1 = horiz ? 4 : 0, ay0 = horiz ? 0 : 3, ay1 = horiz ? 0 : 4;
+    const int sw = ax0 + w + ax1, sh = ay0 + h + ay1, pitch = ((sw + 3) & ~3) + 16;
+    std::vector<char> hs((size_t)pitch * (sh + 1) * se, 0);
+    for (int y = 0; y < sh; y++)
+        memcpy(&hs[((size_t)y * pitch + 4 - ax0) * se],
+               (const char*)src + ((intptr_t)(y - ay0) * src_stride - ax0) * se, (size_t)sw * se);
+    const size_t out_bytes = (size_t)w * h * de;
+    if (int rc = ensure(c, c->stage, hs.size() + 64)) return rc;
+    if (int rc = ensure(c, c->costs, out_bytes)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage.p, hs.data(), hs.size(), hipMemcpyHostToDevice, c->stream));
+    const char *origin = (const char*)c->stage.p + ((size_t)ay0 * pitch + 4) * se;     // element (0,0): column 4 of row ay0
+    const dim3 grid((((w + 3) >> 2) * h + 255) / 256), block(256);
+    if (bpp == 1)
+        hipLaunchKernelGGL(k_ipfilter<uint8_t>, grid, block, 0, c->stream, kind, (const void*)origin, pitch, c->costs.p, w, h, frac, depth);
+    else
+        hipLaunchKernelGGL(k_ipfilter<uint16_t>, grid, block, 0, c->stream, kind, (const void*)origin, pitch, c->costs.p, w, h, frac, depth);
+    HIPCHK(c, hipGetLastError());
+    std::vector<char> ho(out_bytes);
+    HIPCHK(c, hipMemcpyAsync(ho.data(), c->costs.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int y = 0; y < h; y++)
+        memcpy((char*)dst + (intptr_t)y * dst_stride * de, &ho[(size_t)y * w * de], (size_t)w * de);
+    return 0;
 }
 
 int x265amd_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x265amd_block_pair *pairs, int32_t *out)
@@ -1272,7 +1387,11 @@ int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = sync_planes(c)) return rc;
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
-    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out);
+    if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
+    if (int rc = ensure(c, c->items, (size_t)n * sizeof(FullItem))) return rc;
+    if (int rc = ensure(c, c->item_jobs, (size_t)n * sizeof(int))) return rc;
+    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
+                                   (FullBest*)c->fullbest.p, (FullItem*)c->items.p, (int*)c->item_jobs.p);
 }
 
 int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,
@@ -1292,6 +1411,8 @@ int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, in
         joblist_free(c, L);
         return rc;
     }
+    L->n_refs = n_refs;
+    L->h_jobs.assign(jobs, jobs + n);
     *out = L;
     return 0;
 }
@@ -1306,6 +1427,24 @@ int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     if (c->h_planes[enc_plane].bpp != L->bpp)
         return fail(c, X265AMD_ERR_INVALID, "job list was planned for a different pixel size");
+    if (n_refs < L->n_refs)
+        return fail(c, X265AMD_ERR_INVALID, "job list was created for more reference planes than this run supplies");
+    {
+        // the jobs' windows against these planes' margins: checked once per plane geometry
+        std::vector<int64_t> geom;
+        auto push = [&](const PlaneDesc &d) {
+            for (int64_t v : { (int64_t)d.width, (int64_t)d.height, (int64_t)d.margin_x, (int64_t)d.margin_y })
+                geom.push_back(v);
+        };
+        push(c->h_planes[enc_plane]);
+        for (int i = 0; i < L->n_refs; i++)
+            push(c->h_planes[ref_planes[i]]);
+        if (geom != L->checked_geom)
+        {
+            if (int rc = check_job_ranges(c, enc_plane, ref_planes, L->h_jobs.data(), L->n)) return rc;
+            L->checked_geom.swap(geom);
+        }
+    }
     if (int rc = sync_planes(c)) return rc;
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
     if (int rc = joblist_launch(c, L, P)) return rc;
@@ -1320,6 +1459,19 @@ int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *L)
 {
     return L ? (const x265amd_me_result*)L->results.p : nullptr;
+}
+
+int x265amd_joblist_results(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_result *out)
+{
+    if (!c || !L || !out)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!L->ran)
+        return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 // Launch order by job length.  A pattern search's length is data dependent (a far-moving block takes

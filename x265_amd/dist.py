@@ -36,16 +36,19 @@ def broadcast_plane(plane: torch.Tensor, src: int = 0, engine=None) -> torch.Ten
     """Broadcast a padded reference plane (uint8/uint16 tensor, same shape on every rank) from
     `src` to all ranks, in place.  One collective per plane: the planes are small (2.6 MB at
     1080p, 9.3 MB at 4K) and xGMI is point-to-point, so a single direct fan-out beats any
-    per-row or ring schedule.  If `engine` is given, the call first waits for the searches queued
-    on the engine's stream (they may still read the plane) and returns when the copy is complete,
-    so work queued on the engine afterwards sees the new plane.  (PlaneRing overlaps the two.)"""
-    ordered = engine is not None and plane.is_cuda and world() > 1     # (alone, nothing is copied)
+    per-row or ring schedule.  If `engine` is given the copy is ordered against the engine's stream
+    on the GPU: it starts after the searches queued so far (they may still read the plane), and work
+    queued on the engine afterwards starts after it.  The host does not wait.  (PlaneRing overlaps
+    the copy with the searches of the previous frame.)"""
+    grouped = dist.is_available() and dist.is_initialized()
+    ordered = engine is not None and plane.is_cuda and grouped
     if ordered:
-        engine.sync()
-    if world() > 1:
+        cur = torch.cuda.current_stream(plane.device)
+        cur.wait_stream(engine.torch_stream())
+    if grouped:
         dist.broadcast(plane, src=src)
     if ordered:
-        torch.cuda.current_stream(plane.device).synchronize()
+        engine.torch_stream().wait_stream(cur)
     return plane
 
 
@@ -62,18 +65,25 @@ class PlaneRing:
     buffers.  Per frame k the caller runs
         b = ring.acquire(k)        # buffer holding plane k (broadcast by prefetch(k), or now)
         ... queue the search of frame k on the engine, reading buffer b ...
-        ring.prefetch(k + 1)       # overlap=True only: start the next broadcast into the other buffer
-        ring.release(k)            # wait for the search of frame k (and for the prefetch)
-    Every hand-over is a host-side wait: no stream ever waits on another stream's events.
-    With a single rank nothing is copied and nothing waits (searches simply queue up).
+        ring.prefetch(k + 1)       # start the next broadcast into the other buffer, beside the search
+        ring.release(k)            # mark the end of the searches reading buffer b
+    On the GPU every hand-over is an event between two streams - the collective runs on / is joined to
+    torch's current stream, the searches on the engine's stream - and the host never waits:
+      * acquire / prefetch: the broadcast into a buffer starts after the event that release() recorded
+        behind the last search reading that buffer (two frames earlier); the engine's stream then
+        waits for the broadcast's completion event before anything queued later runs;
+      * release(k): records "buffer k & 1 is free again" on the engine's stream.
+    So broadcast k + 1 overlaps search k, and a sequence of steps queues up without host round trips
+    (the caller synchronises once at the end).  With no process group nothing is copied and the ring
+    only hands out buffer indices; with a process group of one rank the collective still runs (it moves
+    nothing), which is how a single GPU exercises this path.
 
-    overlap=False (the default) keeps the collective and the search kernels strictly one after the
-    other.  Overlapping them (prefetch) is implemented but off: a two-rank rehearsal on one GPU
-    (gloo backend, both ranks sharing the device) stopped making progress after some tens of
-    steps whenever a broadcast ran beside the search kernels, and ran clean with the two
-    serialised; until the overlapped form has run on a real multi-GPU node it is not the default."""
+    overlap=False keeps the broadcast of frame k + 1 out of prefetch(): it then starts in acquire(k + 1),
+    behind search k on the engine's stream (serial, still without host waits).
 
-    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = False):
+    On the CPU (gloo tests) the collective is synchronous and there is nothing to order."""
+
+    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = True):
         assert len(buffers) == 2
         self.buffers = list(buffers)
         self.engine = engine
@@ -81,30 +91,52 @@ class PlaneRing:
         self.overlap = overlap
         self.gpu = engine is not None and self.buffers[0].is_cuda
         self.ready = -1                     # index of the newest plane already broadcast
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.free = [None, None]            # per buffer: event behind the last search that read it
+        self.filled = [None, None]          # per buffer: event behind the broadcast that filled it
+        if self.gpu:
+            self.free_pool = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(2)]
+            self.fill_pool = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(2)]
+            self.uses = [0, 0]
 
     def slot(self, k: int) -> int:
         return k & 1
 
     def _broadcast(self, k: int) -> None:
-        dist.broadcast(self.buffers[self.slot(k)], src=self.src)
+        b = self.slot(k)
+        if self.gpu:
+            cur = torch.cuda.current_stream(self.buffers[b].device)
+            if self.free[b] is not None:
+                cur.wait_event(self.free[b])            # the searches of frame k - 2 have read the buffer
+            dist.broadcast(self.buffers[b], src=self.src)
+            ev = self.fill_pool[b][self.uses[b] & 1]
+            ev.record(cur)
+            self.filled[b] = ev
+        else:
+            dist.broadcast(self.buffers[b], src=self.src)
         self.ready = k
 
     def acquire(self, k: int) -> int:
-        if world() > 1 and self.ready < k:
-            self._broadcast(k)
-            if self.gpu:
-                torch.cuda.current_stream(self.buffers[0].device).synchronize()
-        return self.slot(k)
+        b = self.slot(k)
+        if self.collective:
+            if self.ready < k:
+                self._broadcast(k)
+            if self.gpu and self.filled[b] is not None:
+                self.engine.wait_event(self.filled[b])  # searches queued from now on see plane k
+                self.filled[b] = None
+        return b
 
     def prefetch(self, k: int) -> None:
-        if self.overlap and world() > 1 and self.ready < k:
+        if self.overlap and self.collective and self.ready < k:
             self._broadcast(k)
 
     def release(self, k: int) -> None:
-        if world() > 1 and self.gpu:
-            self.engine.sync()
-            if self.overlap:
-                torch.cuda.current_stream(self.buffers[0].device).synchronize()
+        if self.collective and self.gpu:
+            b = self.slot(k)
+            ev = self.free_pool[b][self.uses[b] & 1]
+            self.uses[b] += 1
+            self.engine.record_event(ev)
+            self.free[b] = ev
 
 
 def gather_results(local: np.ndarray, frames: Sequence[int], n_frames: int, dst: int = 0, device=None):

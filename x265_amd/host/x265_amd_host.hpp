@@ -40,15 +40,18 @@ struct MV
 // A registered plane stands in for ReferencePlanes::fpelPlane / lumaStride (common/reference.h:36-53)
 struct ReferencePlanes
 {
-    int plane_id;
-    int lumaStride;
+    int plane_id = -1;
+    int lumaStride = 0;
+    // picture size and margins (TComPicYuv::getWidth / getLumaMarginX ...): what turns the reference's
+    // linear PU offsets back into coordinates (MotionEstimate::setSourcePU)
+    int width = 0, height = 0, marginX = 0, marginY = 0;
 };
 
 // Lowres (common/lowres.h:41-72), picture part: the F/H/V/C half-resolution planes live on the device;
 // as a search reference it behaves as ReferencePlanes with isLowres set
 struct Lowres : ReferencePlanes
 {
-    int width = 0, lines = 0;               // rounded up to whole 8x8 CUs (lowres.cpp:44-46)
+    int lines = 0;                          // width (inherited) and lines, rounded up to whole 8x8 CUs (lowres.cpp:44-46)
     int widthInCU = 0, heightInCU = 0;      // slicetype.cpp:74-75
 };
 
@@ -73,6 +76,15 @@ public:
     {
         ReferencePlanes r;
         check(x265amd_plane_upload(m_ctx, base, width, height, marginX, marginY, stride, bytesPerPixel, bitDepth, &r.plane_id));
+        return describe(r.plane_id);
+    }
+    // the ReferencePlanes of a plane registered through the C ABI (wrapped device memory, row-wise planes)
+    ReferencePlanes describe(int plane_id)
+    {
+        ReferencePlanes r;
+        intptr_t stride = 0;
+        check(x265amd_plane_geometry(m_ctx, plane_id, &r.width, &r.height, &r.marginX, &r.marginY, &stride, NULL, NULL));
+        r.plane_id = plane_id;
         r.lumaStride = (int)stride;
         return r;
     }
@@ -87,6 +99,9 @@ public:
         intptr_t stride = 0;
         check(x265amd_lowres_geometry(m_ctx, l.plane_id, &l.width, &l.lines, &stride, &l.widthInCU, &l.heightInCU));
         l.lumaStride = (int)stride;
+        l.height = l.lines;
+        l.marginX = src.marginX;
+        l.marginY = src.marginY;
         return l;
     }
     // Lowres::init for the next picture held by an existing set
@@ -201,10 +216,12 @@ public:
     void setSourcePlane(const ReferencePlanes &enc) { m_enc = enc; }   // motion.h:78-82
     void setSourcePU(int offset, int pwidth, int pheight)         // motion.h:84: offset = y*stride + x
     {
-        // floor division so that PUs in the padded border (negative y) map back correctly
+        // y = floor(offset / stride) (PUs in the top margin have negative offsets), x in [0, stride).
+        // A column at or beyond width + marginX does not exist in row y: it is a column of the LEFT
+        // margin of row y + 1 (x - stride in [-marginX, 0)).
         int y = offset >= 0 ? offset / m_enc.lumaStride : -((-offset + m_enc.lumaStride - 1) / m_enc.lumaStride);
         int x = offset - y * m_enc.lumaStride;
-        if (x > m_enc.lumaStride / 2) { x -= m_enc.lumaStride; y += 1; }
+        if (x >= m_enc.width + m_enc.marginX) { x -= m_enc.lumaStride; y += 1; }
         m_puX = x; m_puY = y; m_w = pwidth; m_h = pheight;
     }
     void setSourcePUxy(int x, int y, int pwidth, int pheight) { m_puX = x; m_puY = y; m_w = pwidth; m_h = pheight; }
@@ -303,7 +320,7 @@ private:
 
     Context &m_ctx;
     MotionField *m_field = nullptr;
-    ReferencePlanes m_enc = { -1, 0 };
+    ReferencePlanes m_enc;
     int m_method = 3, m_subme = 5;          // the reference's defaults (motion.cpp:82-85)
     unsigned m_qp = 32;
     int m_puX = 0, m_puY = 0, m_w = 0, m_h = 0;
