@@ -210,6 +210,16 @@ int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_plan
 int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                                    const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
 
+/* The same search for callers that must not allocate device memory while they call it (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Identical results to x265amd_me_search_batch_device; the per-job scratch of the exhaustive kernel
+ * (partial winners, work items) lives in a fixed device array inside the library instead of buffers
+ * grown on demand, so: n <= 65536 jobs per call (X265AMD_ERR_INVALID beyond; split the batch); the call
+ * performs no hipMalloc / hipFree; all contexts on one GPU share that GPU's array, so calls that overlap
+ * in time on one GPU (two contexts, two threads) race - serialise them. */
+int x265amd_me_search_batch_device_noalloc(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
+                                           const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
+
 /* Planned job lists.  An encoder searches the same PU geometry frame after frame; a job list
  * keeps the jobs in device memory and plans the exhaustive kernel once (PUs of one size that
  * share a 32x32 cell share one staged search window; large PUs are cut into candidate-row slabs).

@@ -88,6 +88,7 @@ def load_library() -> C.CDLL:
     L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
+    L.x265amd_me_search_batch_device_noalloc.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_joblist_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(vp)]
     L.x265amd_joblist_run.argtypes = [vp, vp, ci, cip, ci, vp]
     L.x265amd_joblist_results_device.argtypes = [vp]
@@ -277,6 +278,11 @@ class Engine:
         """asynchronous: jobs/results are device pointers; call sync() before reading results"""
         refs = (C.c_int * len(ref_planes))(*ref_planes)
         self._chk(self.lib.x265amd_me_search_batch_device(self.h, enc_plane, refs, len(ref_planes), d_jobs_ptr, n, d_out_ptr))
+
+    def search_device_noalloc(self, enc_plane: int, ref_planes, d_jobs_ptr: int, n: int, d_out_ptr: int):
+        """search_device for callers that must not allocate: fixed scratch inside the library, n <= 65536"""
+        refs = (C.c_int * len(ref_planes))(*ref_planes)
+        self._chk(self.lib.x265amd_me_search_batch_device_noalloc(self.h, enc_plane, refs, len(ref_planes), d_jobs_ptr, n, d_out_ptr))
 
     def make_joblist(self, jobs: np.ndarray, n_refs: int = 1, bytes_per_px: int = 1) -> "JobList":
         return JobList(self, jobs, n_refs, bytes_per_px)

@@ -56,6 +56,7 @@ struct x265amd_ctx
     void        *owned[MAX_PLANES];       // device allocation owned by the context (upload) or NULL (wrapped)
     void        *base[MAX_PLANES];        // device address of the padded allocation
     PlaneDesc   *d_planes = nullptr;
+    PlaneDesc   *h_planes_pin = nullptr;  // pinned copy the table is uploaded from (a plain DMA, no staging)
     bool         planes_dirty = true;
 
     std::vector<float>    bitsizes;       // BitCost::s_bitsizes
@@ -159,8 +160,9 @@ int sync_planes(x265amd_ctx *c)
 {
     if (!c->planes_dirty)
         return 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(c->h_planes), hipMemcpyHostToDevice, c->stream));
-    // h_planes may change right after this call returns
+    memcpy(c->h_planes_pin, c->h_planes, sizeof(c->h_planes));
+    HIPCHK(c, hipMemcpyAsync(c->d_planes, c->h_planes_pin, sizeof(c->h_planes), hipMemcpyHostToDevice, c->stream));
+    // the pinned copy may change right after this call returns
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->planes_dirty = false;
     return 0;
@@ -688,6 +690,44 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 
 } // namespace
 
+// ---- scratch of the allocation-free entry point (x265amd_me_search_batch_device_noalloc) ------------
+// One FullBest, one FullItem and one item-job index per job, for up to NOALLOC_MAX_JOBS jobs, in a
+// file-scope device array: every GPU the library runs on holds its own copy (3.25 MiB) at its own
+// address until the process ends.  `scratch` is only a host-side stand-in for the symbol: the device
+// address is looked up once per device (resolve_scratch, called by x265amd_create with that device
+// current) and only that address is ever handed to kernels.
+constexpr int NOALLOC_MAX_JOBS = 65536;
+constexpr size_t NOALLOC_FB_OFF = 0;
+constexpr size_t NOALLOC_ITEMS_OFF = NOALLOC_FB_OFF + sizeof(FullBest) * NOALLOC_MAX_JOBS;
+constexpr size_t NOALLOC_IJOBS_OFF = NOALLOC_ITEMS_OFF + sizeof(FullItem) * NOALLOC_MAX_JOBS;
+constexpr size_t NOALLOC_BYTES = NOALLOC_IJOBS_OFF + sizeof(int) * NOALLOC_MAX_JOBS;
+static_assert(NOALLOC_ITEMS_OFF % 8 == 0 && NOALLOC_IJOBS_OFF % 4 == 0, "scratch carve-up alignment");
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[MAX_DEVICES];       // device address of `scratch` on device i (NULL: not looked up yet)
+
+// with `device` current
+hipError_t resolve_scratch(int device)
+{
+    if (device < 0 || device >= MAX_DEVICES)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (g_scratch_ptr[device])
+        return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess)
+        return e;
+    if (!p)
+        return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = p;
+    return hipSuccess;
+}
+} // namespace
+
 extern "C" {
 
 int x265amd_partition_from_sizes(int w, int h)
@@ -730,6 +770,7 @@ int x265amd_create(int device, x265amd_ctx **out)
     if (e != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->d_planes, sizeof(c->h_planes))) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_planes_pin, sizeof(c->h_planes))) != hipSuccess ||
         (e = hipMalloc(&c->d_cost, (size_t)52 * 65536 * sizeof(uint16_t))) != hipSuccess ||
         (e = hipMalloc(&c->d_evals, EVAL_WORDS * sizeof(unsigned long long))) != hipSuccess)
     {
@@ -768,6 +809,12 @@ int x265amd_create(int device, x265amd_ctx **out)
     }
     if (const char *ev = getenv("X265AMD_LANES"))        // streams the independent kernels of a batch are spread over
         c->n_lanes = std::max(1, std::min(x265amd_ctx::N_AUX + 1, atoi(ev)));
+    if ((e = resolve_scratch(device)) != hipSuccess)
+    {
+        fprintf(stderr, "x265amd_create: address of the scratch array: %s\n", hipGetErrorString(e));
+        x265amd_destroy(c);
+        return X265AMD_ERR_HIP;
+    }
 
     *out = c;
     return X265AMD_OK;
@@ -798,6 +845,8 @@ void x265amd_destroy(x265amd_ctx *c)
         if (c->ev[i])
             hipEventDestroy(c->ev[i]);
     hipFree(c->d_planes);
+    if (c->h_planes_pin)
+        hipHostFree(c->h_planes_pin);
     hipFree(c->d_cost);
     hipFree(c->d_evals);
     for (int i = 0; i < x265amd_ctx::N_AUX; i++)
@@ -1392,6 +1441,32 @@ int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref
     if (int rc = ensure(c, c->item_jobs, (size_t)n * sizeof(int))) return rc;
     return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
                                    (FullBest*)c->fullbest.p, (FullItem*)c->items.p, (int*)c->item_jobs.p);
+}
+
+int x265amd_me_search_batch_device_noalloc(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
+                                           const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out)
+{
+    if (!c || !d_jobs || !d_out || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > NOALLOC_MAX_JOBS)
+    {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "%d jobs exceed the %d the allocation-free entry point has scratch for; split the batch", n, NOALLOC_MAX_JOBS);
+        return fail(c, X265AMD_ERR_INVALID, msg);
+    }
+    if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = sync_planes(c)) return rc;          // (a copy from pinned memory; nothing is allocated)
+    unsigned char *sp = (unsigned char*)g_scratch_ptr[c->device];
+    if (!sp)
+        return fail(c, X265AMD_ERR_HIP, "the scratch array's device address is unknown");
+    BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
+    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
+                                   (FullBest*)(sp + NOALLOC_FB_OFF), (FullItem*)(sp + NOALLOC_ITEMS_OFF),
+                                   (int*)(sp + NOALLOC_IJOBS_OFF));
 }
 
 int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,
