@@ -234,6 +234,38 @@ def test_exhaustive_ties_and_wide_ranges(eng, oracle, bits):
             eng.release_plane(i)
 
 
+@pytest.mark.parametrize("kind", ["motion", "noise", "flat"])
+def test_whole_cell_exhaustive_search_matches_oracle(eng, oracle, kind):
+    """FULL-search jobs on every square of the 64x64 quadtree (8/16/32/64) share one pass over the window
+    (8x8 SADs summed up the tree): whole frames with partial cells at the right / bottom edges (clipped,
+    per-PU different ranges), a non-zero predictor, a subset of the levels, a range of 257 candidates that
+    does not qualify, and flat pictures where every candidate ties and the raster order decides."""
+    W, H = 200, 152
+    if kind == "flat":
+        a = np.full((H, W), 77, np.int32)
+        fr = [synth.pad_plane(a), synth.pad_plane(a)]
+    else:
+        fr = synth.make_sequence(W, H, 2, seed=515, kind=kind)
+    ids = [eng.upload_plane(f) for f in fr]
+    parts = [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=64, qp=32),
+             J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=1, merange=20, qp=24, qmvp=(-37, 22)),
+             J.frame_jobs(W, H, sizes=(32, 8), method=J.FULL, subme=0, merange=13, qp=40, qmvp=(6, 6)),
+             J.frame_jobs(W, H, sizes=(64, 16), method=J.BIPRED, subme=0, merange=4, qp=30, qmvp=(3, -5))]
+    wide = J.frame_jobs(W, H, sizes=(64, 8), method=J.FULL, subme=0, merange=8, qp=30)[:40:3]
+    wide["mvmin_x"], wide["mvmax_x"] = -70, 70               # 141 x 257 candidates: beyond the shared-window kernel's index
+    wide["mvmin_y"], wide["mvmax_y"] = -8, 8
+    parts.append(wide)
+    jobs = np.concatenate(parts)
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8)
+    eng.eval_count(reset=True)
+    got = eng.search(ids[0], [ids[1]], jobs)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_device_resident_and_planned_paths_agree(eng, oracle):
     """The three ways in (host batch, raw device job array, planned job list) give identical,
     oracle-exact results; the job list mixes FULL jobs of every size class with pattern searches."""

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(k, r["Counter_Name"])] += 1
 for k in acc:
-    if "k_search" in k or "k_full" in k:
+    if "k_search" in k or "k_full" in k or "k_pack" in k or "k_field" in k or "k_look" in k:
         for c, v in acc[k].items():
             print("%-62s %-24s %14.0f  (%d dispatches)" % (k, c, v, n[(k, c)]))
 PY

@@ -1,0 +1,524 @@
+// Exhaustive (FULL_SEARCH) integer stage for ALL square PUs of a 64x64 picture cell from ONE pass
+// over the search window (8-bit pixels, SAD metric).
+//
+// SAD is additive over a partition of the block: the SAD of a 16x16 PU at candidate m is the sum of
+// the SADs of its four 8x8 quarters at the same m, and so on up to 64x64 (the reference relies on the
+// same identity when it builds large-block primitives from small ones, common/x86/asm-primitives.cpp:
+// 50-59).  A "bundle" is the set of FULL-search jobs whose PUs are the squares of the quadtree of one
+// 64x64 cell (8x8, 16x16, 32x32, 64x64; any subset) and that share reference, QP and predictor, hence
+// one search window and one MV-cost slice.  Per candidate the kernel measures only the 8x8 cells -
+// a quarter of the pixel-SADs of four independent scans - and sums them up the quadtree in Z-order.
+//
+// Mapping.  A work item = (bundle, range of lane tasks); one 128-thread workgroup stages the window rows
+// those tasks touch into LDS.  A lane task = 4 horizontally adjacent candidates x HIER_R candidate rows:
+// v_qsad_pk_u16_u8 prices the 4 byte-shifted candidates of one 4-pixel group per instruction, every
+// window dword pair read from LDS feeds HIER_R candidate rows, and the encoder pixels arrive as SCALAR
+// operands (the bundle's 64x64 block is re-packed cell by cell in Z-order by k_pack_fenc, so one
+// s_load_dwordx16 fetches a whole 8x8 cell).  Packed 16-bit partial sums hold up to 16x16 (<= 65280);
+// 32x32 and 64x64 continue in 32 bits.
+//
+// Winner per PU = min over (cost, raster index), the candidate the reference's strict-`<` raster scan
+// keeps (encoder/motion.cpp:738-771): as soon as a PU's sums are complete its 4 x HIER_R candidate keys
+// are reduced inside the lane, across the wavefront (DPP) and into a per-wavefront LDS slot - no key
+// lives in registers across cells.  Keys of 8x8 / 16x16 PUs are 32-bit (cost < 2^17 in the top bits,
+// 15-bit raster index of the bundle window below); invalid candidates (beyond the window, or outside
+// a job's own clipped range) get a key at or above HIER_KEY_NONE, which no real candidate reaches.  Slabs of one bundle write
+// partial winners (FullBest) that the general kernel combines, like the slabs of me_full.h.
+#pragma once
+
+#include "me_full.h"
+
+namespace xa {
+
+constexpr int HIER_R = 4;                 // candidate rows per lane task
+constexpr int HIER_THREADS = 128;
+constexpr int HIER_WAVES = HIER_THREADS / 64;
+constexpr int HIER_PUS = 85;              // 64 + 16 + 4 + 1 squares of the quadtree
+constexpr int HIER_SMALL = 80;            // PUs 0..79 (8x8, 16x16) use 32-bit keys
+constexpr int HIER_RIDX_BITS = 15;        // raster index bits: window candidates <= 2^15
+constexpr int HIER_FENC_DW = 1024;        // packed encoder block: 64 cells x 16 dwords
+// 32-bit keys: (SAD + mvcost) << 15 | raster index.  The kernel is used only while no MV-cost table entry
+// exceeds HIER_MVCOST_MAX / 2 (the reference's tables peak at 3381, encoder/bitcost.cpp:48-56 with the
+// largest lambda), so a valid key stays below (65280 + 8191) << 15 | 32767 < HIER_KEY_NONE, and every
+// key at or above HIER_KEY_NONE marks "not a candidate".
+constexpr uint32_t HIER_MVCOST_MAX = 8191;
+constexpr uint32_t HIER_KEY_NONE = 0xE0000000u;
+
+struct HierBundle
+{
+    int32_t  ctu_x, ctu_y;      // picture position of the 64x64 cell
+    int32_t  mvx0, mvy0;        // first candidate MV (full-pel) of the bundle window = union of the jobs' ranges
+    int32_t  nxw, nyw;          // candidates per row / candidate rows of the window
+    int32_t  qmvp_x, qmvp_y;    // the jobs' common predictor (q-pel) and QP
+    int32_t  qp, ref_idx;
+    int32_t  uniform;           // every job's range equals the window (no per-job masking)
+    int32_t  pad;
+    uint64_t cells;             // bit z: 8x8 cell z (Z-order) is covered by some job
+    int32_t  job[HIER_PUS];     // job of square k (0..63: 8x8 in Z-order, 64..79: 16x16, 80..83: 32x32, 84: 64x64), -1: none
+    int32_t  pad2;
+};
+
+// A work item: lane tasks [t_lo, t_hi) of a bundle, in raster order of (row quad, x group)
+struct HierItem
+{
+    int32_t bundle;
+    int32_t t_lo, t_hi;
+    int32_t slot;               // FullBest slot (slab number)
+    int32_t pitch, win_nd;      // LDS row pitch / staged dwords per window row
+    int32_t win_rows;           // window rows staged, from candidate row HIER_R * (t_lo / XG)
+    int32_t pad;
+};
+
+#define XA_CONST __attribute__((address_space(4)))
+
+// Z-order cell index -> cell coordinates inside the 64x64 block
+__device__ __host__ __forceinline__ void hier_cell_xy(int z, int &cx, int &cy)
+{
+    cx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+    cy = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+}
+
+// Re-pack the 64x64 encoder block of every bundle: cell z (Z-order) -> 16 consecutive dwords
+// (row r, half k at [2 r + k]).
+__global__ void __launch_bounds__(256) k_pack_fenc(BatchParams P, const HierBundle *bundles, int n, uint32_t *packed)
+{
+    const int b = blockIdx.x;
+    if (b >= n)
+        return;
+    const PlaneDesc &enc = P.planes[P.enc_plane];
+    const HierBundle &B = bundles[b];
+    const uint8_t *org = (const uint8_t*)enc.origin;
+    for (int i = threadIdx.x; i < HIER_FENC_DW; i += 256)
+    {
+        const int z = i >> 4, r = (i >> 1) & 7, k = i & 1;
+        int cx, cy;
+        hier_cell_xy(z, cx, cy);
+        int64_t o = (int64_t)(B.ctu_y + cy * 8 + r) * enc.stride + B.ctu_x + cx * 8 + 4 * k;
+        o = o < enc.lo ? enc.lo : (o > enc.hi - 4 ? enc.hi - 4 : o);
+        packed[(size_t)b * HIER_FENC_DW + i] = ld_u32(org + o);
+    }
+}
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t hier_min_dpp(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+// minimum over the wavefront; valid in lane 63
+__device__ __forceinline__ uint32_t hier_wave_min_last(uint32_t v)
+{
+    v = hier_min_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v = hier_min_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v = hier_min_dpp<0x141>(v);           // row_half_mirror
+    v = hier_min_dpp<0x140>(v);           // row_mirror
+    v = hier_min_dpp<0x142, 0xa>(v);      // row_bcast15 into rows 1 and 3
+    v = hier_min_dpp<0x143, 0xc>(v);      // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// what a lane knows about its task's 4 x HIER_R candidates
+struct HierCand
+{
+    uint32_t mvr[HIER_R][4];    // (mvcost << 15) + raster index; HIER_KEY_NONE: not a candidate
+};
+
+// D = S0.u16 (low / high half) * S1.u16 + S2.u32 in one instruction
+__device__ __forceinline__ uint32_t hier_mad_lo(uint32_t p, uint32_t mul, uint32_t add)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(mul), "v"(add));
+    return r;
+}
+__device__ __forceinline__ uint32_t hier_mad_hi(uint32_t p, uint32_t mul, uint32_t add)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(p), "s"(mul), "v"(add));
+    return r;
+}
+// the same with the result saturated at 2^32 - 1 (the VOP3 clamp bit saturates this instruction on gfx950:
+// tools/mad_clamp_probe.hip)
+__device__ __forceinline__ uint32_t hier_mad_lo_sat(uint32_t p, uint32_t mul, uint32_t add)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(p), "s"(mul), "v"(add));
+    return r;
+}
+__device__ __forceinline__ uint32_t hier_mad_hi_sat(uint32_t p, uint32_t mul, uint32_t add)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0] clamp" : "=v"(r) : "v"(p), "s"(mul), "v"(add));
+    return r;
+}
+
+// The lane's minimum key of one 8x8 (SMALL8: sums <= 16320, so sum << 15 plus any mvr cannot wrap) or
+// 16x16 PU (sums <= 65280: saturating add) from packed 16-bit sums p[i] (4 candidates of row i), plus
+// optional per-job kill words
+template <bool MASK, bool SMALL8>
+__device__ __forceinline__ uint32_t hier_lane_min32(const unsigned long long *p, const HierCand &c, const uint32_t *kx, const uint32_t *ky)
+{
+    uint32_t m = ~0u;
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+    {
+        const uint32_t lo = (uint32_t)p[i], hi = (uint32_t)(p[i] >> 32);
+        uint32_t k[4];
+        if (SMALL8)
+        {
+            const uint32_t mul = 1u << HIER_RIDX_BITS;
+            k[0] = hier_mad_lo(lo, mul, c.mvr[i][0]); k[1] = hier_mad_hi(lo, mul, c.mvr[i][1]);
+            k[2] = hier_mad_lo(hi, mul, c.mvr[i][2]); k[3] = hier_mad_hi(hi, mul, c.mvr[i][3]);
+        }
+        else
+        {
+            const uint32_t mul = 1u << HIER_RIDX_BITS;
+            k[0] = hier_mad_lo_sat(lo, mul, c.mvr[i][0]); k[1] = hier_mad_hi_sat(lo, mul, c.mvr[i][1]);
+            k[2] = hier_mad_lo_sat(hi, mul, c.mvr[i][2]); k[3] = hier_mad_hi_sat(hi, mul, c.mvr[i][3]);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            if (MASK)
+                k[x] |= kx[x] | ky[i];
+            m = k[x] < m ? k[x] : m;
+        }
+    }
+    return m;
+}
+
+// The lane's best candidate of a 32x32 / 64x64 PU from 32-bit sums, as a 64-bit key (cost << 32 | raster
+// index) for the cross-lane reduction.  Inside the lane the 16 candidates are compared as
+// (cost << 4 | slot), slot = 4 * row + x being their raster order.
+template <bool MASK>
+__device__ __forceinline__ unsigned long long hier_lane_min64(const uint32_t (*s)[4], const HierCand &c, int x0, int y0, int nxw,
+                                                              int jx0, int jx1, int jy0, int jy1)
+{
+    constexpr uint32_t BIG = 0x3ffffffu;            // "not a candidate": above every real cost (< 2^21)
+    uint32_t m = ~0u;
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+    {
+        const bool oky = !MASK || (y0 + i >= jy0 && y0 + i <= jy1);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            const bool ok = c.mvr[i][x] < HIER_KEY_NONE && oky && (!MASK || (x0 + x >= jx0 && x0 + x <= jx1));
+            const uint32_t mv = ok ? c.mvr[i][x] >> HIER_RIDX_BITS : BIG;
+            const uint32_t k = ((s[i][x] + mv) << 4) | (uint32_t)(i * 4 + x);
+            m = k < m ? k : m;
+        }
+    }
+    const uint32_t cost = m >> 4, slot = m & 15;
+    if (cost >= BIG)
+        return ~0ull;
+    return ((unsigned long long)cost << 32) | (uint32_t)((y0 + (int)(slot >> 2)) * nxw + x0 + (int)(slot & 3));
+}
+
+// per-job kill words of the lane's candidates (MASK bundles: a job's own range is smaller than the window)
+template <bool MASK>
+__device__ __forceinline__ void hier_job_mask(const x265amd_me_job *jobs, int jid, const HierBundle &B, int x0, int y0, uint32_t *kx, uint32_t *ky)
+{
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        kx[x] = 0;
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+        ky[i] = 0;
+    if (MASK)
+    {
+        const x265amd_me_job &J = jobs[jid];
+        const int jx0 = J.mvmin_x - B.mvx0, jx1 = J.mvmax_x - B.mvx0, jy0 = J.mvmin_y - B.mvy0, jy1 = J.mvmax_y - B.mvy0;
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            kx[x] = (x0 + x >= jx0 && x0 + x <= jx1) ? 0u : ~0u;
+#pragma unroll
+        for (int i = 0; i < HIER_R; i++)
+            ky[i] = (y0 + i >= jy0 && y0 + i <= jy1) ? 0u : ~0u;
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
+                                               const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
+{
+    constexpr int R = HIER_R;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
+    const int nxw = B.nxw, nyw = B.nyw, pitch = it.pitch;
+    const int XG = (nxw + 3) >> 2;
+    const int yq_lo = it.t_lo / XG;                 // first row quad of this slab = first staged candidate row / R
+
+    // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
+    uint32_t *s_win = lds;
+    uint16_t *s_cx = (uint16_t*)(s_win + it.win_rows * pitch);
+    uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
+    uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
+    unsigned long long *s_big = (unsigned long long*)(s_slot + HIER_WAVES * HIER_SMALL);
+
+    // ---- stage the window rows of this slab, the MV-cost slices, and clear the slots
+    {
+        const uint8_t *r0 = (const uint8_t*)ref.origin;
+        const int64_t lo = ref.lo, hi = ref.hi - 4;
+        const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + R * yq_lo;
+        const int nd = it.win_nd;
+        const int64_t first = (int64_t)wy0 * ref.stride + wx0, last = (int64_t)(wy0 + it.win_rows - 1) * ref.stride + wx0 + 4 * (nd - 1);
+        if (first >= lo && last <= hi)
+        {
+            // the whole window lies inside the plane allocation: plain 32-bit offsets
+            const uint8_t *w0 = r0 + first;
+            const int stride = ref.stride;
+            for (int r = wv; r < it.win_rows; r += HIER_WAVES)
+                for (int c = lane; c < nd; c += 64)
+                    s_win[r * pitch + c] = ld_u32(w0 + r * stride + 4 * c);
+        }
+        else
+        {
+            for (int r = wv; r < it.win_rows; r += HIER_WAVES)
+                for (int c = lane; c < nd; c += 64)
+                {
+                    int64_t a = (int64_t)(wy0 + r) * ref.stride + wx0 + 4 * c;
+                    a = a < lo ? lo : (a > hi ? hi : a);
+                    s_win[r * pitch + c] = ld_u32(r0 + a);
+                }
+        }
+        const uint16_t *cost = P.cost[B.qp];
+        for (int i = tid; i < nxw; i += HIER_THREADS)
+            s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
+        for (int i = tid; i < nyw; i += HIER_THREADS)
+            s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        for (int i = tid; i < HIER_WAVES * HIER_SMALL; i += HIER_THREADS)
+            s_slot[i] = ~0u;
+        if (tid < HIER_WAVES * 5)
+            s_big[tid] = ~0ull;
+    }
+    __syncthreads();
+
+    const uint64_t cells = B.cells;
+    for (int base = it.t_lo; base < it.t_hi; base += HIER_THREADS)
+    {
+        const int task = base + tid;
+        const bool active = task < it.t_hi;
+        const int tk = active ? task : it.t_lo;
+        const int yq = tk / XG, xg = tk - yq * XG;
+        const int x0 = 4 * xg, y0 = R * yq;
+        HierCand C;
+#pragma unroll
+        for (int i = 0; i < R; i++)
+        {
+            const int y = y0 + i;
+            const bool vy = active && y < nyw;
+            const uint32_t cyv = s_cy[y < nyw ? y : nyw - 1];
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int xx = x0 + x;
+                const uint32_t mv = (s_cx[xx < nxw ? xx : nxw - 1] + cyv) & 0xffffu;
+                C.mvr[i][x] = (vy && xx < nxw) ? (mv << HIER_RIDX_BITS) + (uint32_t)(y * nxw + xx) : HIER_KEY_NONE;
+            }
+        }
+        const uint32_t *wbase = s_win + (R * (yq - yq_lo)) * pitch + xg;
+
+        uint32_t a64[R][4], a32[R][4];
+        unsigned long long a16[R];
+#pragma unroll
+        for (int i = 0; i < R; i++)
+        {
+            a16[i] = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                a64[i][x] = a32[i][x] = 0;
+        }
+
+        // the covered cells in Z-order; the next cell's encoder pixels are fetched (scalar loads) while
+        // the current cell is measured
+        uint64_t rem = cells;
+        int z = rem ? __builtin_ctzll(rem) : 64;
+        uint32_t f[16];
+        {
+            const XA_CONST uint32_t *fe = pf + (z & 63) * 16;
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                f[e] = fe[e];
+        }
+#pragma nounroll
+        while (z < 64)
+        {
+            rem &= rem - 1;
+            const int nz = rem ? __builtin_ctzll(rem) : 64;
+            uint32_t fn[16];
+            {
+                const XA_CONST uint32_t *fe = pf + (nz & 63) * 16;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    fn[e] = fe[e];
+            }
+            int cx, cy;
+            hier_cell_xy(z, cx, cy);
+            const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
+            unsigned long long p[R];
+#pragma unroll
+            for (int i = 0; i < R; i++)
+                p[i] = 0;
+#pragma unroll
+            for (int r = 0; r < 8 + R - 1; r++)
+            {
+                const unsigned long long d0 = lds_pair(row + r * pitch), d1 = lds_pair(row + r * pitch + 1);
+#pragma unroll
+                for (int i = 0; i < R; i++)
+                {
+                    const int e = r - i;            // encoder row that window row r meets in candidate row i
+                    if (e >= 0 && e < 8)
+                    {
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d0, f[2 * e], p[i]);
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d1, f[2 * e + 1], p[i]);
+                    }
+                }
+            }
+            // 8x8 PU of this cell
+            const int j8 = B.job[z];
+            if (j8 >= 0)
+            {
+                uint32_t kx[4], ky[R];
+                hier_job_mask<MASK>(jobs, j8, B, x0, y0, kx, ky);
+                const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, true>(p, C, kx, ky));
+                if (lane == 63)
+                {
+                    uint32_t *sl = s_slot + wv * HIER_SMALL + z;
+                    *sl = m < *sl ? m : *sl;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; i++)
+                a16[i] += p[i];         // four 16-bit lanes; no carry between them: every partial 16x16 sum <= 65280
+            if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
+            {
+                const int q = z >> 2;
+                const int j16 = B.job[64 + q];
+                if (j16 >= 0)
+                {
+                    uint32_t kx[4], ky[R];
+                    hier_job_mask<MASK>(jobs, j16, B, x0, y0, kx, ky);
+                    const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, false>(a16, C, kx, ky));
+                    if (lane == 63)
+                    {
+                        uint32_t *sl = s_slot + wv * HIER_SMALL + 64 + q;
+                        *sl = m < *sl ? m : *sl;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < R; i++)
+                {
+                    const uint32_t lo = (uint32_t)a16[i], hi = (uint32_t)(a16[i] >> 32);
+                    a32[i][0] += lo & 0xffffu; a32[i][1] += lo >> 16;
+                    a32[i][2] += hi & 0xffffu; a32[i][3] += hi >> 16;
+                    a16[i] = 0;
+                }
+                if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
+                {
+                    const int q32 = z >> 4;
+                    const int j32 = B.job[80 + q32];
+                    if (j32 >= 0)
+                    {
+                        const x265amd_me_job &J = jobs[j32];
+                        unsigned long long m = hier_lane_min64<MASK>(a32, C, x0, y0, nxw,
+                                                                     J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+                        m = wave_min_u64(m);
+                        if (lane == 0)
+                        {
+                            unsigned long long *sl = s_big + wv * 5 + q32;
+                            *sl = m < *sl ? m : *sl;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                        {
+                            a64[i][x] += a32[i][x];
+                            a32[i][x] = 0;
+                        }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                f[e] = fn[e];
+            z = nz;
+        }
+        const int j64 = B.job[84];
+        if (j64 >= 0)
+        {
+            const x265amd_me_job &J = jobs[j64];
+            unsigned long long m = hier_lane_min64<MASK>(a64, C, x0, y0, nxw,
+                                                         J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+            m = wave_min_u64(m);
+            if (lane == 0)
+            {
+                unsigned long long *sl = s_big + wv * 5 + 4;
+                *sl = m < *sl ? m : *sl;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- one thread per PU combines the wavefronts' winners and writes the slab's partial result
+    if (tid < HIER_PUS)
+    {
+        const int jid = B.job[tid];
+        if (jid >= 0)
+        {
+            FullBest f;
+            int cost = 0x7fffffff, ridx = -1;
+            if (tid < HIER_SMALL)
+            {
+                uint32_t m = ~0u;
+                for (int w = 0; w < HIER_WAVES; w++)
+                {
+                    const uint32_t v = s_slot[w * HIER_SMALL + tid];
+                    m = v < m ? v : m;
+                }
+                if (m < HIER_KEY_NONE)
+                {
+                    cost = (int)(m >> HIER_RIDX_BITS);
+                    ridx = (int)(m & ((1u << HIER_RIDX_BITS) - 1));
+                }
+            }
+            else
+            {
+                unsigned long long m = ~0ull;
+                for (int w = 0; w < HIER_WAVES; w++)
+                {
+                    const unsigned long long v = s_big[w * 5 + (tid - HIER_SMALL)];
+                    m = v < m ? v : m;
+                }
+                if (m != ~0ull)
+                {
+                    cost = (int)(m >> 32);
+                    ridx = (int)(m & 0xffffffffu);
+                }
+            }
+            f.cost = cost;
+            f.mvx = ridx < 0 ? 0 : (int16_t)(B.mvx0 + ridx % nxw);
+            f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
+            fb[(size_t)jid * fb_stride + it.slot] = f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+                                                            const HierItem *items, int n_items, const uint32_t *packed,
+                                                            FullBest *fb, int fb_stride)
+{
+    extern __shared__ uint32_t lds[];
+    const int id = blockIdx.x;
+    if (id >= n_items)
+        return;
+    const HierItem &it = items[id];
+    const HierBundle &B = bundles[it.bundle];
+    const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HIER_FENC_DW);
+    if (B.uniform)
+        hier_item_body<false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    else
+        hier_item_body<true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+}
+
+} // namespace xa

@@ -2,6 +2,7 @@
 // Everything computes on the GPU; there is no host fallback.
 #include "me_kernels.h"
 #include "me_full.h"
+#include "me_hier.h"
 #include "me_lowres.h"
 
 #include <math.h>
@@ -67,6 +68,7 @@ struct x265amd_ctx
     DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
+    bool   hier_ok = false;               // the MV-cost tables are small enough for the hierarchical kernel's 32-bit keys
     bool   timing = false;
     int    flags = 0;
     bool   timed_full = false, timed_any = false;
@@ -91,6 +93,9 @@ struct x265amd_joblist
     std::vector<x265amd_me_job> h_jobs;   // host copy, for the range check against the planes of a run
     std::vector<int64_t> checked_geom;    // geometry of the planes the ranges were last checked against
     DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
+    DevBuf  hier_bundles, hier_items, hier_fenc;      // whole-cell bundles of the hierarchical exhaustive kernel
+    int     n_hier_bundles = 0, n_hier_items = 0, hier_lds_bytes = 0;
+    bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
     bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
@@ -510,6 +515,120 @@ void xcd_interleave(std::vector<T> &v)
     v.swap(out);
 }
 
+// ---- plan of the hierarchical exhaustive kernel (me_hier.h) -----------------------------------
+// Bundles: FULL-search SAD jobs on 8-bit planes whose PUs are squares of the quadtree of one 64x64
+// picture cell and that share reference, QP and predictor.  A bundle is used when measuring its 8x8
+// cells once is clearly less work than scanning every job on its own; its candidate rows are cut into
+// slabs of about one lane task (4 candidates x HIER_R rows) per thread.
+void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in_bundle,
+               std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes)
+{
+    lds_bytes = 0;
+    if (bpp != 1)
+        return;
+    auto fl = [](int v) { return v >= 0 ? v / 64 : -((-v + 63) / 64); };
+    auto zidx = [](int cx, int cy) {
+        return (cx & 1) | ((cy & 1) << 1) | ((cx & 2) << 1) | ((cy & 2) << 2) | ((cx & 4) << 2) | ((cy & 4) << 3); };
+    std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_me_job &j = jobs[i];
+        if (!full_kernel_eligible(j, bpp) || j.w != j.h || (j.w != 8 && j.w != 16 && j.w != 32 && j.w != 64))
+            continue;
+        const int gx = fl(j.pu_x), gy = fl(j.pu_y);
+        if ((j.pu_x - gx * 64) % j.w || (j.pu_y - gy * 64) % j.h)
+            continue;
+        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
+    }
+    for (auto &g : groups)
+    {
+        HierBundle B;
+        memset(&B, 0, sizeof(B));
+        for (int k = 0; k < HIER_PUS; k++)
+            B.job[k] = -1;
+        const int gy = std::get<4>(g.first), gx = std::get<5>(g.first);
+        int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
+        double old_work = 0;
+        std::vector<int> taken;
+        for (int i : g.second)
+        {
+            const x265amd_me_job &j = jobs[i];
+            const int cx = (j.pu_x - gx * 64) >> 3, cy = (j.pu_y - gy * 64) >> 3, z = zidx(cx, cy);
+            const int k = j.w == 8 ? z : j.w == 16 ? 64 + (z >> 2) : j.w == 32 ? 80 + (z >> 4) : 84;
+            if (B.job[k] >= 0)
+                continue;               // the same PU twice: the second one is scanned on its own
+            B.job[k] = i;
+            taken.push_back(i);
+            for (int yy = 0; yy < (j.h >> 3); yy++)
+                for (int xx = 0; xx < (j.w >> 3); xx++)
+                    B.cells |= 1ull << zidx(cx + xx, cy + yy);
+            x0 = std::min(x0, (int)j.mvmin_x); y0 = std::min(y0, (int)j.mvmin_y);
+            x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
+            old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1);
+        }
+        if (taken.size() < 2)
+            continue;
+        const int nxw = x1 - x0 + 1, nyw = y1 - y0 + 1;
+        if ((int64_t)nxw * nyw > (1 << HIER_RIDX_BITS))
+            continue;
+        const double hier_work = (double)__builtin_popcountll(B.cells) * 64.0 * nxw * nyw;
+        if (hier_work * 1.25 > old_work)
+            continue;
+        B.uniform = 1;
+        for (int i : taken)
+            if (jobs[i].mvmin_x != x0 || jobs[i].mvmax_x != x1 || jobs[i].mvmin_y != y0 || jobs[i].mvmax_y != y1)
+                B.uniform = 0;
+        const x265amd_me_job &j0 = jobs[taken[0]];
+        B.ctu_x = gx * 64; B.ctu_y = gy * 64;
+        B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
+        B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
+        // slabs of about one lane task per thread
+        const int XG = (nxw + 3) >> 2, nd = XG + 16;
+        int pitch = nd, best = 64;
+        for (int p = nd; p < nd + 32; p++)
+        {
+            const int d = ((HIER_R * p - XG) % 32 + 32) % 32, dd = std::min(d, 32 - d);
+            if (dd < best)
+            {
+                best = dd;
+                pitch = p;
+            }
+        }
+        // slabs of one lane task per thread (more per thread only when that would exceed the FullBest slots)
+        const int nquads = (nyw + HIER_R - 1) / HIER_R, ntasks = nquads * XG;
+        int per = HIER_THREADS;
+        while ((ntasks + per - 1) / per > FB_STRIDE_PLAN)
+            per += HIER_THREADS;
+        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * HIER_WAVES * HIER_SMALL + 8 * HIER_WAVES * 5 + 64;
+        bool fits = true;
+        std::vector<HierItem> mine;
+        for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
+        {
+            HierItem it;
+            memset(&it, 0, sizeof(it));
+            it.bundle = (int)bundles.size();
+            it.t_lo = t;
+            it.t_hi = std::min(ntasks, t + per);
+            it.slot = slot;
+            it.pitch = pitch;
+            it.win_nd = nd;
+            it.win_rows = ((it.t_hi - 1) / XG - it.t_lo / XG + 1) * HIER_R + 63;
+            const int bytes = 4 * it.win_rows * pitch + fixed;
+            fits = fits && bytes <= FULL_LDS_MAX;
+            lds_bytes = std::max(lds_bytes, bytes);
+            mine.push_back(it);
+        }
+        if (!fits)
+            continue;
+        for (int i : taken)
+            in_bundle[i] = 1;
+        bundles.push_back(B);
+        items.insert(items.end(), mine.begin(), mine.end());
+    }
+    if (bundles.empty())
+        lds_bytes = 0;
+}
+
 int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs, int n, int bpp)
 {
     L->n = n;
@@ -547,13 +666,31 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
             HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
         }
     }
+    std::vector<char> in_bundle(n, 0);
+    std::vector<HierBundle> hbundles;
+    std::vector<HierItem> hitems;
+    L->n_hier_bundles = L->n_hier_items = L->hier_lds_bytes = 0;
+    if (c->hier_ok && !(c->flags & 16)) // (tuning aid: X265AMD_FLAGS bit 4 switches the hierarchical kernel off)
+        plan_hier(jobs, n, bpp, in_bundle, hbundles, hitems, L->hier_lds_bytes);
+    if (!hitems.empty())
+    {
+        // picture order, dealt to the XCDs in contiguous bands (bundles were made in (row, column) order)
+        xcd_interleave(hitems);
+        L->n_hier_bundles = (int)hbundles.size();
+        L->n_hier_items = (int)hitems.size();
+        if (int rc = ensure(c, L->hier_bundles, hbundles.size() * sizeof(HierBundle))) return rc;
+        if (int rc = ensure(c, L->hier_items, hitems.size() * sizeof(HierItem))) return rc;
+        if (int rc = ensure(c, L->hier_fenc, hbundles.size() * (size_t)HIER_FENC_DW * 4)) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->hier_bundles.p, hbundles.data(), hbundles.size() * sizeof(HierBundle), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L->hier_items.p, hitems.data(), hitems.size() * sizeof(HierItem), hipMemcpyHostToDevice, c->stream));
+    }
     std::vector<PlannedItem> planned;
     {
         std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
         for (int i = 0; i < n; i++)
         {
             const x265amd_me_job &j = jobs[i];
-            if (!full_kernel_eligible(j, bpp))
+            if (!full_kernel_eligible(j, bpp) || in_bundle[i])
                 continue;
             if (j.w * j.h <= 256)
             {
@@ -566,6 +703,19 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         }
         for (auto &g : groups)
             plan_group(jobs, bpp, g.second, planned);
+    }
+    L->has_fb = !planned.empty() || !hitems.empty();
+    if (L->has_fb)
+    {
+        std::vector<FullBest> fb((size_t)n * FB_STRIDE_PLAN);
+        for (FullBest &f : fb)
+        {
+            f.cost = 0x7fffffff;
+            f.mvx = f.mvy = 0;
+        }
+        if (int rc = ensure(c, L->fb, fb.size() * sizeof(FullBest))) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->fb.p, fb.data(), fb.size() * sizeof(FullBest), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // fb dies here
     }
     if (!planned.empty())
     {
@@ -603,16 +753,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
             item_jobs.insert(item_jobs.end(), p.members.begin(), p.members.end());
             items.push_back(p.it);
         }
-        std::vector<FullBest> fb((size_t)n * FB_STRIDE_PLAN);
-        for (FullBest &f : fb)
-        {
-            f.cost = 0x7fffffff;
-            f.mvx = f.mvy = 0;
-        }
-        if (int rc = ensure(c, L->fb, fb.size() * sizeof(FullBest))) return rc;
         if (int rc = ensure(c, L->items, items.size() * sizeof(FullItem))) return rc;
         if (int rc = ensure(c, L->item_jobs, item_jobs.size() * sizeof(int))) return rc;
-        HIPCHK(c, hipMemcpyAsync(L->fb.p, fb.data(), fb.size() * sizeof(FullBest), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L->items.p, items.data(), items.size() * sizeof(FullItem), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L->item_jobs.p, item_jobs.data(), item_jobs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -623,7 +765,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist };
+    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
+                       &L->hier_bundles, &L->hier_items, &L->hier_fenc };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -633,10 +776,21 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 // the exhaustive-kernel launches of a planned list
 int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
-    const int lanes = (int)std::min<size_t>(L->launches.size(), c->n_lanes);
+    const int lanes = (int)std::min<size_t>(L->launches.size() + (L->n_hier_items ? 1 : 0), c->n_lanes);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     int k = 0;
+    if (L->n_hier_items)
+    {
+        hipStream_t st = c->lane(k++);
+        hipLaunchKernelGGL(k_pack_fenc, dim3(L->n_hier_bundles), dim3(256), 0, st, P, (const HierBundle*)L->hier_bundles.p,
+                           L->n_hier_bundles, (uint32_t*)L->hier_fenc.p);
+        hipLaunchKernelGGL(k_full_hier, dim3(L->n_hier_items), dim3(HIER_THREADS), L->hier_lds_bytes, st, P,
+                           (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->hier_bundles.p,
+                           (const HierItem*)L->hier_items.p, L->n_hier_items, (const uint32_t*)L->hier_fenc.p,
+                           (FullBest*)L->fb.p, FB_STRIDE_PLAN);
+        HIPCHK(c, hipGetLastError());
+    }
     for (const x265amd_joblist::Launch &la : L->launches)
     {
         hipStream_t st = c->lane(k++);
@@ -675,7 +829,7 @@ int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams 
     L->ran = true;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
-                          L->launches.empty() ? nullptr : (const FullBest*)L->fb.p, FB_STRIDE_PLAN,
+                          L->has_fb ? (const FullBest*)L->fb.p : nullptr, FB_STRIDE_PLAN,
                           (x265amd_me_result*)L->results.p, timing_events);
 }
 
@@ -683,7 +837,7 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
     if (int rc = record_start(c)) return rc;
     if (int rc = joblist_launch_full(c, L, P)) return rc;
-    c->timed_full = !L->launches.empty();
+    c->timed_full = L->has_fb;
     return joblist_launch_search(c, L, P, true);
 }
 
@@ -779,6 +933,13 @@ int x265amd_create(int device, x265amd_ctx **out)
         return X265AMD_ERR_HIP;
     }
     build_cost_tables(c);
+    {
+        unsigned mx = 0;
+        for (int q = 0; q < 52; q++)
+            for (uint16_t v : c->h_cost[q])
+                mx = std::max(mx, (unsigned)v);
+        c->hier_ok = 2 * mx <= HIER_MVCOST_MAX;
+    }
     for (int q = 0; q < 52; q++)
         if ((e = hipMemcpy(c->d_cost + (size_t)q * 65536, c->h_cost[q].data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess)
         {
@@ -790,7 +951,7 @@ int x265amd_create(int device, x265amd_ctx **out)
 #define XA_FULL_KERNELS(PIX) (const void*)k_full_items<0, PIX>, (const void*)k_full_items<1, PIX>, (const void*)k_full_items<2, PIX>, \
                              (const void*)k_full_items<3, PIX>, (const void*)k_full_items<4, PIX>, (const void*)k_full_items<6, PIX>, \
                              (const void*)k_full_items<8, PIX>, (const void*)k_full_items<12, PIX>, (const void*)k_full_items<16, PIX>
-    const void *full_kernels[] = { XA_FULL_KERNELS(uint8_t), XA_FULL_KERNELS(uint16_t) };
+    const void *full_kernels[] = { XA_FULL_KERNELS(uint8_t), XA_FULL_KERNELS(uint16_t), (const void*)k_full_hier };
 #undef XA_FULL_KERNELS
     e = hipSuccess;
     for (const void *k : full_kernels)
