@@ -2,28 +2,31 @@
 """Motion-estimation benchmark (one JSON line on rank 0).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: one rank per GPU over RCCL; started by torch.distributed.run, or by this script itself
+     when it is invoked plainly with --gpus N)
 
 A step = one whole-frame ME pass of the hot path on every rank:
   * rank 0 owns the reconstructed reference plane; with N > 1 it is broadcast to the other
-    ranks over RCCL (the path's only exchange step), then
+    ranks over RCCL (the path's only exchange step) through a two-buffer ring whose hand-overs are
+    stream events (the next broadcast runs beside the current frame's searches), then
   * every rank searches ITS OWN current 1080p frame (frame rank+1 of the synthetic sequence)
     against that reference -- frames are independent, so the work is sharded with no other
     collective (weak scaling: one frame per GPU per step).
 
-Workload of `value` (BASELINE.json configs[1]): 1920x1080 8-bit, HEX search, merange 64, +-64
-window rule of the encoder, subme 5 (8 half-pel + 8 quarter-pel SATD), PUs 16x16 and 64x64.
-The same run also measures configs[0] on the GPU (FULL +-64 SAD, PUs 64/32/16/8) and reports it
-under "full_search", with the SAD-ALU roofline the exhaustive kernel is bound by.
+Workload of `value` (BASELINE.json's metric "evals/sec and frames/sec, 1080p, +-64 search"; configs[0] on
+the GPU): 1920x1080 8-bit, 64x64 CTUs, exhaustive +-64 integer search with the SAD metric for every square
+PU of the quadtree (64/32/16/8: 42 900 PUs, 7.0e8 block-cost evaluations per frame), subme 0.
+Secondary legs of the same run (N = 1): BASELINE configs[1] (HEX / DIA search + quarter-pel SATD
+refinement), the lookahead path, the PCIe-inclusive rate, and the reference's CPU paths on the host cores.
 
 Planes, job lists and result buffers are resident in HBM before the timed region starts.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -48,60 +51,46 @@ def build_job_lists():
     return hex_jobs, full_jobs
 
 
-def cpu_baseline(enc, ref, hex_jobs, full_jobs, budget_s=20.0):
-    """Time the CPU path on the host cores for a bounded sample of the same workloads.
-    kind 'reference' = the reference's own C path (oracle/_ref, compiled from the reference's
-    sources), 1 thread; falls back to kind 'port' (oracle/libme_oracle.so) if it is absent."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_ffi as F
-    oracle = F.Oracle()
-    out = {}
+def pixel_sads(full_jobs):
+    return float(sum(J.full_search_evals(full_jobs[full_jobs["w"] == s]) * s * s for s in (64, 32, 16, 8)))
 
-    def time_ref(jobs):
-        lib = F.Reference(8)
-        mv = np.zeros((len(jobs), 2), dtype=np.int16)
-        cost = np.zeros(len(jobs), dtype=np.int32)
-        jb = np.ascontiguousarray(jobs)
-        lib.lib.ref_me_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t,
-                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        t0 = time.perf_counter()
-        lib.lib.ref_me_search_batch(lib.me, F.plane_origin(enc), enc.shape[1], F.plane_origin(ref), ref.shape[1],
-                                    jb.ctypes.data, len(jb), mv.ctypes.data, cost.ctypes.data)
-        dt = time.perf_counter() - t0
-        res = np.zeros(len(jobs), dtype=J.RESULT_DTYPE)
-        res["mvx"], res["mvy"], res["cost"] = mv[:, 0], mv[:, 1], cost
-        return dt, res
 
-    def time_port(jobs, threads):
-        t0 = time.perf_counter()
-        res, evals = oracle.search(enc, [ref], jobs, threads=threads)
-        return time.perf_counter() - t0, res, evals
-
-    kind = "reference" if F.have_reference(8) else "port"
-    # HEX workload: the whole frame's job list is ~0.2 s of CPU work; repeat a fixed sample
-    hs = hex_jobs[::2]
-    _, _, hex_evals = time_port(hs[:64], 1)
-    reps, dt = 0, 0.0
-    while dt < budget_s * 0.5 and reps < 200:
-        d, res = time_ref(hs) if kind == "reference" else time_port(hs, 1)[:2]
-        dt += d
-        reps += 1
-    _, chk, hex_evals = time_port(hs, 8)
-    assert np.array_equal(chk, res), "CPU baseline legs disagree"
-    out["hex"] = {"value": hex_evals * reps / dt, "unit": "evals/s", "cores": 1, "kind": kind,
-                  "sample": "%d of %d jobs of the HEX+subme5 frame (every 2nd), %d repetitions, %.1f s" % (len(hs), len(hex_jobs), reps, dt)}
-    # FULL workload: ~0.15 s per 64x64 PU on one core -> a strided sample of PUs of all four sizes
-    fs = np.concatenate([full_jobs[full_jobs["w"] == s][:: st] for s, st in ((64, 3), (32, 6), (16, 12), (8, 24))])
-    d, res = time_ref(fs) if kind == "reference" else time_port(fs, 1)[:2]
-    fe = J.full_search_evals(fs)
-    px = float((J.full_search_evals(fs[fs["w"] == 64]) * 4096 + J.full_search_evals(fs[fs["w"] == 32]) * 1024 +
-                J.full_search_evals(fs[fs["w"] == 16]) * 256 + J.full_search_evals(fs[fs["w"] == 8]) * 64))
-    out["full"] = {"value": fe / d, "unit": "evals/s", "pixel_sads_per_s": px / d, "cores": 1, "kind": kind,
-                   "sample": "%d PUs (strided over 64/32/16/8) of the FULL+-64 frame, %.1f s" % (len(fs), d)}
-    # all host cores given to this job, on the port (one search state per thread)
+def cpu_baseline(budget_s=6.0):
+    """The reference's own CPU paths (oracle/_ref: compiled from the reference's sources) on the host cores,
+    on bounded samples of the same job lists (oracle/cpu_baseline_worker.py, one process per core):
+    C primitives and the intrinsic (SSE4.1-dispatched) primitives, one core and all cores given to this job."""
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
+    have = {k: os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libx265ref%s.so" % k)) for k in ("8", "8v")}
+    if not have["8"]:
+        return None
     cores = min(16, os.cpu_count() or 1)
-    d, _, ev = time_port(hs, cores)
-    out["hex_mt"] = {"value": ev / d, "unit": "evals/s", "cores": cores, "kind": "port"}
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+
+    def run(kind, leg, procs, seconds, evals=None):
+        cmd = [sys.executable, worker, kind, leg, str(seconds)] + ([str(evals)] if evals else [])
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+        return [json.loads(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in ps]
+
+    out = {}
+    for leg in ("full", "hex"):
+        one = run("8", leg, 1, budget_s)[0]
+        per_pass = one["evals"] / one["reps"]
+        sample = "%d jobs of the %s frame (strided), %d passes, %.1f s" % (one["jobs"], "FULL +-64" if leg == "full" else "HEX+subme5",
+                                                                          one["reps"], one["seconds"])
+        out[leg] = {"c_1core": {"value": one["evals"] / one["seconds"], "unit": "evals/s", "cores": 1, "kind": "reference",
+                                "path": "C primitives (cpuid=1)", "sample": sample,
+                                "pixel_sads_per_s": one["pixel_sads"] / one["seconds"] if leg == "full" else None}}
+        if have["8v"]:
+            v1 = run("8v", leg, 1, budget_s / 2, per_pass)[0]
+            assert v1["crc"] == one["crc"], "the reference's C and intrinsic paths disagree"
+            out[leg]["vec_1core"] = {"value": v1["evals"] / v1["seconds"], "unit": "evals/s", "cores": 1, "kind": "reference",
+                                     "path": "intrinsic primitives, the reference's run-time dispatch (up to SSE4.1)",
+                                     "sample": "same sample, %d passes, %.1f s" % (v1["reps"], v1["seconds"]),
+                                     "pixel_sads_per_s": v1["pixel_sads"] / v1["seconds"] if leg == "full" else None}
+            vn = run("8v", leg, cores, budget_s / 2, per_pass)
+            out[leg]["vec_all_cores"] = {"value": sum(o["evals"] for o in vn) / max(o["seconds"] for o in vn), "unit": "evals/s",
+                                         "cores": cores, "kind": "reference",
+                                         "path": "intrinsic primitives, one process (one MotionEstimate) per core, each on the same sample"}
     return out
 
 
@@ -116,11 +105,22 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--full-steps", type=int, default=10)
     ap.add_argument("--only-primary", action="store_true",
-                    help="run only the HEX+subme5 leg `value` is quoted on (for profiler runs: every launch of the "
-                         "search kernels then belongs to that leg) and print a reduced line")
+                    help="run only the leg `value` is quoted on (for profiler runs: every launch of the search "
+                         "kernels then belongs to that leg) and print a reduced line")
+    ap.add_argument("--primary", choices=("full", "hex"), default="full",
+                    help="with --only-primary: which leg to run alone (profiling aid; `value` is always the FULL leg otherwise)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start one rank per GPU ourselves (before anything touches the GPU)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        port = 29400 + (os.getpid() % 500)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
 
     import torch
     import torch.distributed as dist
@@ -172,6 +172,7 @@ def main():
     trace("job lists planned")
     from x265_amd import dist as xd
 
+    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=not os.environ.get("X265AMD_NO_OVERLAP"))
     if os.environ.get("X265AMD_BENCH_TRACE"):       # a watchdog: what is busy when a rank stops making progress
         import threading
 
@@ -185,11 +186,10 @@ def main():
                          [ev(e) for e in ring.filled], ring.ready))
         threading.Thread(target=watchdog, daemon=True).start()
 
-    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=not os.environ.get("X265AMD_NO_OVERLAP"))
     step_no = [0]
 
     def step(jl):
-        # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame
+        # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame; no host waits
         k = step_no[0]
         step_no[0] += 1
         b = ring.acquire(k)
@@ -214,7 +214,7 @@ def main():
         barrier()
         trace("timed region starts")
         # HIP events bracket the kernels of the LAST step only: timestamp events drain the queue between
-        # launches, and with them in every step the back-to-back frames run about 7 % slower
+        # launches, and with them in every step the back-to-back frames run a few per cent slower
         eng.set_timing(False)
         t0 = time.perf_counter()
         for k in range(steps):
@@ -236,29 +236,83 @@ def main():
             evals = float(e.item())
         return dt, evals, k_full, k_search
 
-    # ---- primary: HEX + subme 5 ------------------------------------------------------------
-    dt, evals, _, k_search_ms = timed(jl_hex, args.warmup, args.steps)
-    hex_res = jl_hex.run(enc_id, [ref_id], fetch=True)
-    value = evals / dt
-    ms_per_step = dt / args.steps * 1e3
-    # algorithmic HBM bytes of one launch: enc plane + ref plane read once, jobs read, results written
-    alg_bytes = 2 * ref_np.nbytes + hex_jobs.nbytes + len(hex_jobs) * 8
-    achieved_gbs = alg_bytes / (k_search_ms * 1e-3) / 1e9
+    def pmc(key):
+        f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            return json.load(open(f)).get(key)
+        except Exception:
+            return None
 
-    # ---- the same kernel against the integer-ALU roof: algorithmic operations of one frame ------------
-    # (1 SAD evaluation of a w x h block = w*h operations, 1 SATD evaluation = 5*w*h; the split per PU size
-    # comes from the evaluation counter of one run per size)
-    alg_ops = 0.0
-    for size in (16, 64):
-        js = hex_jobs[hex_jobs["w"] == size]
-        jl_s = eng.make_joblist(js)
-        eng.eval_count(reset=True)
-        jl_s.run(enc_id, [ref_id], fetch=False)
-        ev = eng.eval_count(reset=True)
-        jl_s.close()
-        satd = 17 * len(js)
-        alg_ops += ((ev - satd) + 5 * satd) * size * size
-    eng.set_timing(True)
+    prop = torch.cuda.get_device_properties(local_rank)
+    cus = prop.multi_processor_count
+    clk_hz = prop.clock_rate * 1e3 if hasattr(prop, "clock_rate") else 2.4e9
+    sad_peak = cus * SAD_LANES_PER_CLK_PER_CU * 4 * clk_hz
+    alg_bytes = 2 * ref_np.nbytes                 # enc plane + ref plane read once (jobs / results added per leg)
+
+    # ---- primary: FULL +-64 SAD, every square PU of the quadtree ---------------------------------
+    run_full = not (args.only_primary and args.primary == "hex")
+    run_hex = (world == 1) and not (args.only_primary and args.primary == "full")
+    full = hexr = None
+    if run_full:
+        fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, args.warmup, args.steps)
+        full_res = jl_full.run(enc_id, [ref_id], fetch=True)
+        px_alg = pixel_sads(full_jobs)                    # 1 evaluation of a w x h block = w*h pixel-SADs, no credit for reuse
+        px_exec = float(J.full_search_evals(full_jobs[full_jobs["w"] == 8]) * 64)      # measured: the 8x8 cells only
+        full_bytes = alg_bytes + full_jobs.nbytes + len(full_jobs) * 8
+        full = {
+            "value": fevals / fdt, "ms_per_step": fdt / args.steps * 1e3, "frames_per_s": world * args.steps / fdt,
+            "evals_per_frame": fevals / (args.steps * world),
+            "roofline": {"bound": "valu", "kernel": "k_full_hier", "achieved": px_alg / (k_full_ms * 1e-3) / 1e12, "peak": sad_peak / 1e12,
+                         "unit": "T pixel-SAD/s", "frac": px_alg / (k_full_ms * 1e-3) / sad_peak,
+                         "traffic": pmc("k_full_hier_bytes_per_launch"),
+                         "kernel_ms": k_full_ms, "search_kernel_ms": k_tail_ms,
+                         "kernel_ms_is": "HIP-event bracket on the engine's stream around the exhaustive kernels (k_pack_fenc + k_full_hier) "
+                                         "of the last step of the timed region; search_kernel_ms: the same around the general kernel "
+                                         "(predictors, slab combine, half-pel SAD round, final SATD)",
+                         "algorithmic_pixel_sads_per_launch": px_alg,
+                         "executed_pixel_sads_per_launch": px_exec,
+                         "executed_frac": px_exec / (k_full_ms * 1e-3) / sad_peak,
+                         "note": "achieved / frac use the ALGORITHMIC work (every PU's candidates x its own pixels, 1.35e11 per frame); the kernel "
+                                 "measures only the 8x8 cells and sums them up the quadtree (executed = a quarter), so frac can exceed 1; "
+                                 "executed_frac is the instruction-level utilisation of the packed-SAD pipe",
+                         "peak_def": "%d CUs x %d lanes/clk x 4 px (v_sad_u8 / v_qsad_pk_u16_u8) x %.2f GHz" % (cus, SAD_LANES_PER_CLK_PER_CU, clk_hz / 1e9)},
+            "roofline_hbm": {"bound": "hbm", "kernel": "k_full_hier", "achieved": full_bytes / (k_full_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": full_bytes / (k_full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": full_bytes, "traffic": pmc("k_full_hier_bytes_per_launch")},
+        }
+    if run_hex:
+        hdt, hevals, _, k_hex_ms = timed(jl_hex, args.warmup, args.steps)
+        hex_res = jl_hex.run(enc_id, [ref_id], fetch=True)
+        hex_bytes = alg_bytes + hex_jobs.nbytes + len(hex_jobs) * 8
+        # algorithmic operations (1 SAD evaluation of a w x h block = w*h, 1 SATD evaluation = 5*w*h; the split
+        # per PU size comes from the evaluation counter of one run per size)
+        alg_ops = 0.0
+        for size in (16, 64):
+            js = hex_jobs[hex_jobs["w"] == size]
+            jl_s = eng.make_joblist(js)
+            eng.eval_count(reset=True)
+            jl_s.run(enc_id, [ref_id], fetch=False)
+            ev = eng.eval_count(reset=True)
+            jl_s.close()
+            satd = 17 * len(js)
+            alg_ops += ((ev - satd) + 5 * satd) * size * size
+        eng.set_timing(True)
+        hexr = {
+            "workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 half-pel + 8 quarter-pel SATD), PUs 16x16 + 64x64 "
+                        "(BASELINE configs[1])",
+            "value": hevals / hdt, "unit": "evals/s", "ms_per_frame": hdt / args.steps * 1e3, "frames_per_s": args.steps / hdt,
+            "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": hevals / args.steps,
+            "satd_evals_per_frame": 17 * int(len(hex_jobs)), "sad_evals_per_frame": hevals / args.steps - 17 * int(len(hex_jobs)),
+            # a search is a chain of dependent evaluation calls: instruction issue and per-call latency bind it,
+            # so it is priced against the un-packed 32-bit integer-ALU roof (CUs x 64 lanes x clock) and against HBM
+            "roofline": {"bound": "valu", "kernel": "k_search<uint8_t>", "achieved": alg_ops / (k_hex_ms * 1e-3) / 1e12,
+                         "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s", "frac": alg_ops / (k_hex_ms * 1e-3) / (cus * 64 * clk_hz),
+                         "kernel_ms": k_hex_ms, "algorithmic_ops_per_launch": alg_ops,
+                         "ops_def": "SAD evaluation = w*h, SATD evaluation = 5*w*h integer operations"},
+            "roofline_hbm": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": hex_bytes / (k_hex_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hex_bytes / (k_hex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": hex_bytes, "traffic": pmc("k_search_u8_bytes_per_launch")},
+        }
 
     # ---- the exchange step alone (N > 1): reference plane from rank 0 to every rank ----------------
     bcast_us = None
@@ -267,53 +321,55 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             xd.broadcast_plane(ref_bufs[0], 0, engine=eng)
+        eng.sync()
         barrier()
         t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e6], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         bcast_us = float(t.item())
 
+    if args.only_primary and args.primary == "hex":
+        if rank == 0:
+            print(json.dumps({"metric": "ME block-cost evals/sec", "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "note": "HEX leg alone (--only-primary --primary hex: profiling aid)", **hexr}), flush=True)
+        return
+
+    line = {
+        "metric": "ME block-cost evals/sec",
+        "value": full["value"],
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": full["ms_per_step"],
+        "frames_per_s": full["frames_per_s"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "1080p synthetic 8-bit, 64x64 CTUs, exhaustive +-64 integer search (SAD) of every square PU 64/32/16/8, "
+                               "subme 0 (BASELINE configs[0] on the GPU); one frame per GPU per step; reference plane broadcast from rank 0",
+                   "jobs_per_frame": int(len(full_jobs)), "evals_per_frame": full["evals_per_frame"],
+                   "qp": QP, "merange": MERANGE, "parallelism": "frames sharded over %d GPU(s)" % world,
+                   # the collective alone, host-bracketed (it is also inside every timed step, beside the searches)
+                   "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
+        "roofline": full["roofline"],
+        "roofline_hbm": full["roofline_hbm"],
+        "cpu_baseline": None,
+    }
+
     # With N > 1 only the leg `value` is quoted on runs (plus the broadcast alone): the secondary legs are
     # single-GPU figures, and every extra step on N ranks is one more collective per rank for nothing.
     if args.only_primary or world > 1:
         if rank == 0:
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("k_search_u8_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            print(json.dumps({
-                "metric": "ME block-cost evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-                "frames_per_s": world * args.steps / dt, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                "config": {"workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 hpel + 8 qpel SATD), PUs 16x16+64x64 "
-                                       "(BASELINE configs[1]); one frame per GPU per step; reference plane broadcast from rank 0",
-                           "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": evals / (args.steps * world),
-                           "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world,
-                           "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
-                "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                             "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                             "kernel_ms_is": "HIP-event bracket around the search kernels of the last step of the timed region"},
-                "cpu_baseline": None,
-                "note": "primary leg only (--only-primary, or N > 1: cpu_baseline and the secondary legs are reported at N = 1)"}),
-                flush=True)
+            line["note"] = "primary leg only (--only-primary, or N > 1: cpu_baseline and the secondary legs are reported at N = 1)"
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # ---- informational: launch order by job length (x265amd_joblist_rebalance).  The bench repeats one
-    # frame, so the lengths learnt from a run predict the next run exactly - an upper bound for the
-    # technique, not part of `value` (the synthetic sequence draws each frame's local motion afresh, and
-    # an order learnt on frame t does not help frame t + 1 there).
-    jl_reb = eng.make_joblist(hex_jobs)
-    jl_reb.run(enc_id, [ref_id], fetch=False)
-    jl_reb.rebalance()
-    rdt, revals, _, k_reb_ms = timed(jl_reb, 2, args.steps)
-    jl_reb.close()
+    line["hex_search"] = hexr
 
     # ---- the same frame with the diamond search (the other method BASELINE configs[1] names) ----
     dia_jobs = hex_jobs.copy()
@@ -321,42 +377,34 @@ def main():
     jl_dia = eng.make_joblist(dia_jobs)
     ddt, devals, _, k_dia_ms = timed(jl_dia, 2, args.steps)
     jl_dia.close()
+    line["dia_search"] = {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
+                          "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms}
 
     # ---- PCIe-inclusive: both planes uploaded and the MV/cost field downloaded every frame -------
     enc_pin = torch.from_numpy(enc_np).pin_memory()
     ref_pin = torch.from_numpy(ref_np).pin_memory()
-    def pcie_step():
+
+    def pcie_step(jl):
         enc_t.copy_(enc_pin, non_blocking=True)
-        if rank == 0:
-            ref_t.copy_(ref_pin, non_blocking=True)
+        ref_t.copy_(ref_pin, non_blocking=True)
         eng.torch_stream().wait_stream(torch.cuda.current_stream(dev))
-        return jl_hex.run(enc_id, [ref_id], fetch=True)        # blocks until the results are on the host
-    for _ in range(2):
-        pcie_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pcie_step()
-    barrier()
-    pcie_dt = time.perf_counter() - t0
+        return jl.run(enc_id, [ref_id], fetch=True)        # blocks until the results are on the host
 
-    # ---- secondary: FULL +-64 (configs[0] on the GPU) --------------------------------------
-    fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, 2, args.full_steps)
-    full_res = jl_full.run(enc_id, [ref_id], fetch=True)
-    prop = torch.cuda.get_device_properties(local_rank)
-    cus = prop.multi_processor_count
-    clk_hz = prop.clock_rate * 1e3 if hasattr(prop, "clock_rate") else 2.4e9
-    px_per_frame = float(sum(J.full_search_evals(full_jobs[full_jobs["w"] == s]) * s * s for s in (64, 32, 16, 8)))
-    sad_peak = cus * SAD_LANES_PER_CLK_PER_CU * 4 * clk_hz
-    full_px_rate = px_per_frame / (k_full_ms * 1e-3)
+    pcie = {}
+    for name, jl, ev in (("full_search", jl_full, full["evals_per_frame"]), ("hex_search", jl_hex, hexr["evals_per_frame"])):
+        for _ in range(2):
+            pcie_step(jl)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pcie_step(jl)
+        barrier()
+        d = time.perf_counter() - t0
+        pcie[name] = {"ms_per_frame": d / args.steps * 1e3, "frames_per_s": args.steps / d, "value": ev * args.steps / d, "unit": "evals/s"}
+    line["pcie_inclusive"] = {"workload": "enc and ref planes copied host->device and the MV/cost field device->host every frame, "
+                                          "frames not overlapped", **pcie}
 
-    if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    # ---- lookahead path (rank 0 only, not part of `value`): half-resolution plane sets and whole-frame
+    # ---- lookahead path (not part of `value`): half-resolution plane sets and whole-frame
     # neighbour-predicted searches with the reference's lookahead settings (HEX, subme 1, merange 16, qp 12)
     LOOK_PAIRS = 16
     lr_enc, lr_ref = eng.lowres_create(enc_id), eng.lowres_create(ref_id)
@@ -375,73 +423,13 @@ def main():
         look[n] = (eng.kernel_times()[1], eng.eval_count())
     look_field = eng.lookahead_me([lr_enc], [lr_ref])[0]
     _, _, _, look_cw, look_ch = eng.lowres_geometry(lr_enc)
-
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("k_search_u8_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    line = {
-        "metric": "ME block-cost evals/sec",
-        "value": value,
-        "unit": "evals/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "frames_per_s": world * args.steps / dt,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u8",
-        "data": "synthetic",
-        "config": {"workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 hpel + 8 qpel SATD), PUs 16x16+64x64 "
-                               "(BASELINE configs[1]); one frame per GPU per step; reference plane broadcast from rank 0",
-                   "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": evals / (args.steps * world),
-                   # subme 5 = 1 + 8 + 8 SATD evaluations per PU (encoder/motion.cpp:57); the rest are SADs
-                   "satd_evals_per_frame": 17 * int(len(hex_jobs)),
-                   "sad_evals_per_frame": evals / (args.steps * world) - 17 * int(len(hex_jobs)),
-                   "qp": QP, "parallelism": "frames sharded over %d GPU(s)" % world,
-                   # the collective alone, host-bracketed (it is also inside every timed step)
-                   "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
-        "roofline": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": k_search_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel_ms_is": "HIP-event bracket around the search kernels of the last step of the timed region"},
-        # the bound that actually binds this kernel is instruction issue, not memory: the same launch against
-        # the un-packed 32-bit integer-ALU roof (CUs x 64 lanes x clock)
-        "roofline_valu": {"bound": "valu", "kernel": "k_search<uint8_t>", "achieved": alg_ops / (k_search_ms * 1e-3) / 1e12,
-                          "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s",
-                          "frac": alg_ops / (k_search_ms * 1e-3) / (cus * 64 * clk_hz),
-                          "algorithmic_ops_per_launch": alg_ops,
-                          "ops_def": "SAD evaluation = w*h, SATD evaluation = 5*w*h integer operations"},
-        "rebalanced_same_frame": {"workload": "the primary leg again after x265amd_joblist_rebalance (longest jobs of the previous "
-                                              "run start first); the bench repeats one frame, so this is the technique's upper bound",
-                                  "value": revals / rdt, "unit": "evals/s", "ms_per_step": rdt / args.steps * 1e3, "kernel_ms": k_reb_ms},
-        "dia_search": {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
-                       "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms},
-        "pcie_inclusive": {"workload": "HEX+subme5 frame; enc and ref planes copied host->device and the MV/cost field "
-                                       "device->host every frame, frames not overlapped",
-                           "frames_per_s": world * args.steps / pcie_dt, "ms_per_frame": pcie_dt / args.steps * 1e3,
-                           "value": evals / args.steps / world * (world * args.steps / pcie_dt), "unit": "evals/s"},
-        "full_search": {"workload": "1080p 8-bit, FULL +-64 SAD, PUs 64/32/16/8, subme 0 (BASELINE configs[0] on the GPU)",
-                        "value": fevals / fdt, "unit": "evals/s", "frames_per_s": world * args.full_steps / fdt,
-                        "ms_per_frame": fdt / args.full_steps * 1e3, "jobs_per_frame": int(len(full_jobs)),
-                        "roofline": {"bound": "valu", "kernel": "k_full_u8", "achieved": full_px_rate / 1e12, "peak": sad_peak / 1e12,
-                                     "unit": "T pixel-SAD/s", "frac": full_px_rate / sad_peak, "kernel_ms": k_full_ms,
-                                     "search_kernel_ms": k_tail_ms,
-                                     "peak_def": "%d CUs x %d lanes/clk x 4 px (v_sad_u8) x %.2f GHz" % (cus, SAD_LANES_PER_CLK_PER_CU, clk_hz / 1e9)}},
-        "lookahead": {"workload": "1080p 8-bit -> 960x544 half-resolution sets; whole-frame searches of %d x %d 8x8 CUs with the "
-                                  "neighbour-predicted MV chain, HEX + subme 1, merange 16, qp 12 (the reference's lookahead settings)"
-                                  % (look_cw, look_ch),
-                      "pairs_per_call": LOOK_PAIRS, "kernel_ms_per_call": look[LOOK_PAIRS][0],
-                      "frame_pairs_per_s": LOOK_PAIRS / (look[LOOK_PAIRS][0] * 1e-3),
-                      "value": look[LOOK_PAIRS][1] / (look[LOOK_PAIRS][0] * 1e-3), "unit": "evals/s",
-                      "single_pair_kernel_ms": look[1][0], "lowres_init_us_per_picture": lowres_us},
-    }
+    line["lookahead"] = {"workload": "1080p 8-bit -> 960x544 half-resolution sets; whole-frame searches of %d x %d 8x8 CUs with the "
+                                     "neighbour-predicted MV chain, HEX + subme 1, merange 16, qp 12 (the reference's lookahead settings)"
+                                     % (look_cw, look_ch),
+                         "pairs_per_call": LOOK_PAIRS, "kernel_ms_per_call": look[LOOK_PAIRS][0],
+                         "frame_pairs_per_s": LOOK_PAIRS / (look[LOOK_PAIRS][0] * 1e-3),
+                         "value": look[LOOK_PAIRS][1] / (look[LOOK_PAIRS][0] * 1e-3), "unit": "evals/s",
+                         "single_pair_kernel_ms": look[1][0], "lowres_init_us_per_picture": lowres_us}
 
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -458,24 +446,31 @@ def main():
             line["lookahead"]["cpu_baseline"] = {"value": look[1][1] / cpu_dt, "unit": "evals/s", "cores": 1, "kind": "reference",
                                                  "ms_per_frame_pair": cpu_dt * 1e3, "sample": "one 1080p frame pair"}
             line["lookahead"]["parity_ok"] = bool(np.array_equal(cpu_field, look_field))
-        cb = cpu_baseline(enc_np, ref_np, hex_jobs, full_jobs)
-        line["cpu_baseline"] = cb["hex"]
-        line["cpu_baseline_full_search"] = cb["full"]
-        line["cpu_baseline_all_cores"] = cb["hex_mt"]
+        cb = cpu_baseline()
+        if cb is not None:
+            # the stated baseline = the fastest of the reference's CPU paths that builds here, on one core;
+            # the other rows sit beside it
+            best = cb["full"].get("vec_1core", cb["full"]["c_1core"])
+            line["cpu_baseline"] = dict(best, workload="FULL +-64 leg")
+            line["cpu_baseline_all"] = cb
+            line["hex_search"]["cpu_baseline"] = cb["hex"].get("vec_1core", cb["hex"]["c_1core"])
+        else:
+            o = F.Oracle()
+            fs = np.ascontiguousarray(full_jobs[::400])
+            t0 = time.perf_counter()
+            _, ev = o.search(enc_np, [ref_np], fs, threads=1)
+            d = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": ev / d, "unit": "evals/s", "cores": 1, "kind": "port",
+                                    "sample": "%d jobs of the FULL +-64 frame (every 400th), %.1f s" % (len(fs), d)}
         # the GPU and CPU legs ran the same jobs: their results must agree (checker, not product)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_ffi as F
         o = F.Oracle()
         chk, _ = o.search(enc_np, [ref_np], hex_jobs[::5], threads=8)
-        line["parity_sample_ok"] = bool(np.array_equal(chk, hex_res[::5]))
+        ok = bool(np.array_equal(chk, hex_res[::5]))
         fsel = np.arange(0, len(full_jobs), 400)
         chk, _ = o.search(enc_np, [ref_np], full_jobs[fsel], threads=8)
-        line["parity_sample_ok"] = line["parity_sample_ok"] and bool(np.array_equal(chk, full_res[fsel]))
+        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, full_res[fsel]))
 
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

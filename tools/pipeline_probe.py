@@ -12,8 +12,12 @@ dev = torch.device("cuda", 0)
 base = synth.base_frame(W, H)
 ref = synth.pad_plane(base); enc = synth.pad_plane(synth.moved_frame(base, 1))
 et = torch.from_numpy(enc).to(dev); rt = torch.from_numpy(ref).to(dev)
-jobs = J.frame_jobs(W, H, sizes=(64, 16), method=J.HEX, subme=5, merange=64, qp=32)
-for depth in (1, 2, 3, 4):
+leg = sys.argv[1] if len(sys.argv) > 1 else "hex"
+if leg == "full":
+    jobs = J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=64, qp=32)
+else:
+    jobs = J.frame_jobs(W, H, sizes=(64, 16), method=J.HEX, subme=5, merange=64, qp=32)
+for depth in (1, 2, 3):
     engs = [Engine(0) for _ in range(depth)]
     ctx = []
     for e in engs:

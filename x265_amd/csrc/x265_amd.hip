@@ -77,7 +77,7 @@ struct x265amd_ctx
     // side on auxiliary streams, so that one launch's tail overlaps the others: fork() makes the
     // auxiliary streams wait for the main one, join() the reverse.
     static constexpr int N_AUX = 3;
-    int n_lanes = N_AUX + 1;               // streams in use: 1 .. N_AUX + 1 (X265AMD_LANES)
+    int n_lanes = 2;                       // streams in use: 1 .. N_AUX + 1 (X265AMD_LANES); two give the overlap, more only cost hardware queues
     hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
     x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
