@@ -168,6 +168,22 @@ typedef struct x265amd_block_pair
 int x265amd_cost_batch(x265amd_ctx *ctx, int kind, int w, int h, int n,
                        const x265amd_block_pair *pairs, int32_t *out);
 
+/* n costs of motion-compensated blocks: out[i] = sad / satd / sa8d_inter of the w x h PU at (pu_x, pu_y) of
+ * enc_plane against the prediction block of the same position displaced by the q-pel MV in ref_plane,
+ * interpolated like TComPrediction::xPredInterLumaBlk (Lib/TLibCommon/TComPrediction.cpp:464-496).  With
+ * X265AMD_SAD this is the distortion term of TEncSearch::xGetTemplateCost (the AMVP candidate check,
+ * Lib/TLibEncoder/TEncSearch.cpp:2944-2958: xPredInterLumaBlk + m_me.bufSAD), with X265AMD_SA8D that of
+ * the uni-directional merge candidates and xGetInterPredictionError (:2182-2190: motionCompensation +
+ * m_me.bufSA8D).  The caller clips the MVs (TComDataCU::clipMv) as those call sites do. */
+typedef struct x265amd_mc_pair
+{
+    int32_t enc_plane, pu_x, pu_y;
+    int32_t ref_plane, qmv_x, qmv_y;
+} x265amd_mc_pair;
+
+int x265amd_mc_cost_batch(x265amd_ctx *ctx, int kind, int w, int h, int n,
+                          const x265amd_mc_pair *pairs, int32_t *out);
+
 /* ---- batched motion search ------------------------------------------------------------
  * One job == one MotionEstimate::motionEstimate call (encoder/motion.h:95,
  * encoder/motion.cpp:277-866) preceded by setQP / setSearchMethod / setSubpelRefine /
@@ -262,6 +278,28 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *ctx
  * X265AMD_ERR_HIP if a CU row gave up waiting for the row below it (its field is then not valid).
  * The synchronous form of x265amd_lookahead_me (out != NULL) performs this check itself. */
 int x265amd_lookahead_status(x265amd_ctx *ctx);
+
+/* ---- whole-frame motion field with the encoder's predictor chain -------------------------------
+ * The searches TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2341-2455) would run for a
+ * picture cut into a uniform grid of pu_w x pu_h PUs (2Nx2N PUs of CUs of that size, those fully inside
+ * the picture), each against `ref_plane`, in raster order, every search centred on a predictor derived ON
+ * THE DEVICE from the final MVs of the PU's already searched neighbours:
+ *   - AMVP candidates: A = left MV; B = the first that exists of the above-right, above, above-left MV;
+ *     B dropped if equal to A; padded with zero vectors to two (xEstimateMvPredAMVP's list, without the
+ *     temporal candidate);
+ *   - mvp = the candidate with the smaller xGetTemplateCost (:2944-2958): SAD of the PU against the
+ *     motion-compensated (interpolated) block at the candidate after TComDataCU::clipMv; ties keep A;
+ *   - [mvmin, mvmax] = xSetSearchRange(mvp, merange) (:3007-3024, no frame-parallel row clamp);
+ *   - motionEstimate(ref, mvmin, mvmax, mvp, 3, {left, above, above-right MV or zero}, merange, ...)
+ *     (:2429 / :2445; m_mvPredictors of :2366-2368).
+ * out[gx + gy * (width / pu_w)] = (outQMv, return value) of that PU; out_mvp (optional) receives the
+ * predictor each search used as (x, y) int16 pairs - the key under which a call site finds the result.
+ * Reference planes need margins of at least 78 pixels (X265AMD_ERR_RANGE otherwise).
+ * out == NULL: asynchronous, results stay in device memory (x265amd_field_results_device; valid until the
+ * next x265amd_field_me on the context; x265amd_lookahead_status reports a row that gave up waiting). */
+int x265amd_field_me(x265amd_ctx *ctx, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method,
+                     int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
+const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last
  * reset (one sad/satd/sa8d of a w x h block == 1; sad_x4 == 4); blocks until the stream is idle */

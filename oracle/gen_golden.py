@@ -32,8 +32,29 @@ class RefIp:
         return dst
 
 
+class RefChain:
+    def __init__(self, ref):
+        self.ref = ref
+
+    def field_run(self, enc, refp, pw, ph, mr, method, subme, qp):
+        return self.ref.field_me(enc, refp, pw, ph, mr, method, subme, qp)
+
+
+def gen_chain():
+    """whole-frame fields with predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me)"""
+    for bits in (8, 16):
+        ref = Reference(bits)
+        ref.set_bit_depth(8 if bits == 8 else 10)
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_u%d.npz" % bits), **G.run_chain_suite(RefChain(ref), bits))
+        print("chain fields, bits", bits)
+
+
 def main():
     os.makedirs(G.GOLDEN_DIR, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":
+        gen_chain()
+        return
+    gen_chain()
     for bits in (8, 16):
         ref = Reference(bits)
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "prim_u%d.npz" % bits), **G.run_prim_suite(ref, bits))

@@ -109,6 +109,13 @@ void meo_lowres_init(const void *src, intptr_t src_stride, int bytes_per_px, voi
 int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, int cuh, int merange,
                          int method, int subme, int qp, meo_result *out);
 
+/* the searches of TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2341-2455) for a uniform grid of
+ * pu_w x pu_h PUs in raster order, predictor and candidates from the already searched neighbours (AMVP list
+ * left / first of above-right, above, above-left; the one with the smaller template SAD; xSetSearchRange);
+ * out[gx + gy * (pic_w / pu_w)], out_mvp (optional) = the predictor used, (x, y) pairs; returns the evaluations */
+int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int merange,
+                     int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
+
 /* run n jobs (one enc plane, jobs[i].ref_idx selects refs[]) with `threads` OpenMP threads
  * (one search state per thread); returns total number of block-cost evaluations. */
 int64_t meo_search_batch(const meo_plane *enc, const meo_plane *refs, const meo_job *jobs, int n,

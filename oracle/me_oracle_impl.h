@@ -1104,3 +1104,89 @@ static int64_t SUF(lookahead_me)(const meo_plane *enc, const meo_plane *ref, int
     free(st);
     return evals;
 }
+
+/* ---------------------------------------------------------------- whole-frame field, predInterSearch's chain */
+
+static inline int SUF(clipi)(int v, int lo, int hi)
+{
+    v = v > hi ? hi : v;
+    return v < lo ? lo : v;
+}
+
+/* The searches of TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2341-2455) for a uniform grid of
+ * pu_w x pu_h PUs in raster order: AMVP candidates A = left MV, B = first of above-right / above / above-left MV
+ * (dropped if equal to A), zero-padded to two; mvp = the one with the smaller template SAD at the clipMv'ed
+ * candidate (xEstimateMvPredAMVP :2767-2819, xGetTemplateCost :2944-2958, TComDataCU::clipMv
+ * TComDataCU.cpp:2724-2736; equal index bits, ties keep the first); range = xSetSearchRange (:3007-3024);
+ * motionEstimate with the three neighbour MVs m_mvPredictors (:2366-2368) as candidates. */
+static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h,
+                             int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
+{
+    SUF(state) *st = (SUF(state)*)malloc(sizeof(SUF(state)));
+    int64_t evals = 0;
+    const int gw = pic_w / pu_w, gh = pic_h / pu_h, max_cu = 64;
+    for (int gy = 0; gy < gh; gy++)
+    {
+        for (int gx = 0; gx < gw; gx++)
+        {
+            const int xy = gx + gy * gw, px = gx * pu_w, py = gy * pu_h;
+            const int have_l = gx > 0, have_a = gy > 0, have_ar = gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
+            int c[2][2] = { { 0, 0 }, { 0, 0 } };
+            int bx = 0, by = 0, have_b = 0;
+            if (have_ar)      { bx = out[xy - gw + 1].mvx; by = out[xy - gw + 1].mvy; have_b = 1; }
+            else if (have_a)  { bx = out[xy - gw].mvx;     by = out[xy - gw].mvy;     have_b = 1; }
+            else if (have_al) { bx = out[xy - gw - 1].mvx; by = out[xy - gw - 1].mvy; have_b = 1; }
+            if (have_l)
+            {
+                c[0][0] = out[xy - 1].mvx; c[0][1] = out[xy - 1].mvy;
+                if (have_b && !(bx == c[0][0] && by == c[0][1]))
+                {
+                    c[1][0] = bx; c[1][1] = by;
+                }
+            }
+            else if (have_b)
+            {
+                c[0][0] = bx; c[0][1] = by;
+            }
+            const int xmax = (pic_w + 8 - px - 1) << 2, xmin = (-max_cu - 8 - px + 1) << 2;
+            const int ymax = (pic_h + 8 - py - 1) << 2, ymin = (-max_cu - 8 - py + 1) << 2;
+            SUF(bind)(st, enc, ref, px, py, pu_w, pu_h, qp);
+            int mvpx = c[0][0], mvpy = c[0][1];
+            if (c[1][0] != c[0][0] || c[1][1] != c[0][1])
+            {
+                const int t0 = SUF(subpel_cmp)(st, SUF(clipi)(c[0][0], xmin, xmax), SUF(clipi)(c[0][1], ymin, ymax), MEO_SAD);
+                const int t1 = SUF(subpel_cmp)(st, SUF(clipi)(c[1][0], xmin, xmax), SUF(clipi)(c[1][1], ymin, ymax), MEO_SAD);
+                if (t1 < t0)
+                {
+                    mvpx = c[1][0]; mvpy = c[1][1];
+                }
+            }
+            evals += st->evals;
+            meo_job j;
+            memset(&j, 0, sizeof(j));
+            j.pu_x = px; j.pu_y = py; j.w = (int16_t)pu_w; j.h = (int16_t)pu_h;
+            const int cpx = SUF(clipi)(mvpx, xmin, xmax), cpy = SUF(clipi)(mvpy, ymin, ymax);
+            j.mvmin_x = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpx - (merange << 2)), xmin, xmax) >> 2);
+            j.mvmin_y = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpy - (merange << 2)), ymin, ymax) >> 2);
+            j.mvmax_x = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpx + (merange << 2)), xmin, xmax) >> 2);
+            j.mvmax_y = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpy + (merange << 2)), ymin, ymax) >> 2);
+            j.qmvp_x = (int16_t)mvpx; j.qmvp_y = (int16_t)mvpy;
+            j.merange = (int16_t)merange; j.method = (uint8_t)method; j.subme = (uint8_t)subme; j.qp = (uint8_t)qp;
+            j.numc = 3;
+            if (have_l)  { j.mvc[0][0] = out[xy - 1].mvx;      j.mvc[0][1] = out[xy - 1].mvy; }
+            if (have_a)  { j.mvc[1][0] = out[xy - gw].mvx;     j.mvc[1][1] = out[xy - gw].mvy; }
+            if (have_ar) { j.mvc[2][0] = out[xy - gw + 1].mvx; j.mvc[2][1] = out[xy - gw + 1].mvy; }
+            SUF(bind)(st, enc, ref, px, py, pu_w, pu_h, qp);
+            out[xy].cost = SUF(search)(st, &j, &out[xy].mvx, &out[xy].mvy);
+            evals += st->evals;
+            if (out_mvp)
+            {
+                out_mvp[2 * xy] = (int16_t)mvpx;
+                out_mvp[2 * xy + 1] = (int16_t)mvpy;
+            }
+        }
+    }
+    free(st);
+    return evals;
+}
+

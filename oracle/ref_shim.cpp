@@ -373,6 +373,114 @@ unsigned ref_bipred_search(void *h, pixel *enc, intptr_t encStride, pixel *ref, 
     return bcost;
 }
 
+/* Driver for the motion searches of TEncSearch::predInterSearch over a uniform PU grid (TEncSearch.cpp itself
+ * needs the whole encoder to link): the call sequence of :2364-2368, :2392, :2428-2429 around the reference's
+ * own MotionEstimate, with xEstimateMvPredAMVP's choice (:2767-2819) made through the reference's bufSAD and
+ * interpolation primitives exactly as xGetTemplateCost / xPredInterLumaBlk do (:2944-2958,
+ * TComPrediction.cpp:464-496), TComDataCU::clipMv (TComDataCU.cpp:2724-2736) and xSetSearchRange (:3007-3024).
+ * The AMVP list is the uniform-grid case: A = left MV, B = first of above-right / above / above-left MV, B
+ * dropped if equal to A, zero-padded to two; both index costs are one bit (xGetMvpIdxBits), ties keep the first. */
+static inline void shim_clip(MV &mv, int picw, int pich, int px, int py)
+{
+    int xmax = (picw + 8 - px - 1) << 2, xmin = (-64 - 8 - px + 1) << 2;
+    int ymax = (pich + 8 - py - 1) << 2, ymin = (-64 - 8 - py + 1) << 2;
+    mv.x = (int16_t)X265_MIN(xmax, X265_MAX(xmin, (int)mv.x));
+    mv.y = (int16_t)X265_MIN(ymax, X265_MAX(ymin, (int)mv.y));
+}
+
+void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh,
+                  int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
+{
+    RefME *r = (RefME*)h;
+    r->me.setQP(qp);
+    r->me.setSearchMethod(method);
+    r->me.setSubpelRefine(subme);
+    r->me.setSourcePlane(enc, stride);
+    r->planes.fpelPlane = ref;
+    r->planes.lumaStride = (int)stride;
+    r->planes.isLowres = false;
+    r->planes.lowresPlane[0] = ref;
+    const int gw = picw / puw, gh = pich / puh;
+    MV *mvs = new MV[gw * gh];
+    ALIGN_VAR_32(pixel, pred[64 * 64]);
+    short *tmp = new short[64 * (64 + 7)];
+    for (int gy = 0; gy < gh; gy++)
+    {
+        for (int gx = 0; gx < gw; gx++)
+        {
+            const int xy = gx + gy * gw, px = gx * puw, py = gy * puh;
+            const int puOffset = px + py * (int)stride;
+            r->me.setSourcePU(puOffset, puw, puh);
+            const bool haveL = gx > 0, haveA = gy > 0, haveAR = gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
+            MV mvPredictors[3];                        // left, above, above-right (zero when absent)
+            if (haveL)  mvPredictors[0] = mvs[xy - 1];
+            if (haveA)  mvPredictors[1] = mvs[xy - gw];
+            if (haveAR) mvPredictors[2] = mvs[xy - gw + 1];
+            MV cand[2], b;
+            bool haveB = haveAR || haveA || haveAL;
+            if (haveAR) b = mvs[xy - gw + 1]; else if (haveA) b = mvs[xy - gw]; else if (haveAL) b = mvs[xy - gw - 1];
+            if (haveL)
+            {
+                cand[0] = mvs[xy - 1];
+                if (haveB && b != cand[0]) cand[1] = b;
+            }
+            else if (haveB)
+                cand[0] = b;
+            MV mvp = cand[0];
+            if (cand[1] != cand[0])
+            {
+                unsigned bestCost = 0x7fffffff;
+                for (int i = 0; i < 2; i++)
+                {
+                    MV mv = cand[i];
+                    shim_clip(mv, picw, pich, px, py);
+                    pixel *src = ref + puOffset + (mv.x >> 2) + (mv.y >> 2) * stride;
+                    int xFrac = mv.x & 3, yFrac = mv.y & 3;
+                    unsigned cost;
+                    if (!(xFrac | yFrac))
+                    {
+                        primitives.blockcpy_pp(puw, puh, pred, 64, src, stride);
+                        cost = r->me.bufSAD(pred, 64);
+                    }
+                    else
+                    {
+                        if (!yFrac)
+                            primitives.ipfilter_pp[FILTER_H_P_P_8](src, stride, pred, 64, puw, puh, g_lumaFilter[xFrac]);
+                        else if (!xFrac)
+                            primitives.ipfilter_pp[FILTER_V_P_P_8](src, stride, pred, 64, puw, puh, g_lumaFilter[yFrac]);
+                        else
+                        {
+                            primitives.ipfilter_ps[FILTER_H_P_S_8](src - 3 * stride, stride, tmp, puw, puw, puh + 7, g_lumaFilter[xFrac]);
+                            primitives.ipfilter_sp[FILTER_V_S_P_8](tmp + 3 * puw, puw, pred, 64, puw, puh, g_lumaFilter[yFrac]);
+                        }
+                        cost = r->me.bufSAD(pred, 64);
+                    }
+                    if (bestCost > cost)
+                    {
+                        bestCost = cost;
+                        mvp = cand[i];
+                    }
+                }
+            }
+            MV cmvp = mvp;
+            shim_clip(cmvp, picw, pich, px, py);
+            MV dist((int16_t)(merange << 2), (int16_t)(merange << 2));
+            MV mvmin = cmvp - dist, mvmax = cmvp + dist;
+            shim_clip(mvmin, picw, pich, px, py);
+            shim_clip(mvmax, picw, pich, px, py);
+            mvmin >>= 2;
+            mvmax >>= 2;
+            out_cost[xy] = r->me.motionEstimate(&r->planes, mvmin, mvmax, mvp, 3, mvPredictors, merange, mvs[xy]);
+            out_mv[2 * xy] = mvs[xy].x;
+            out_mv[2 * xy + 1] = mvs[xy].y;
+            out_mvp[2 * xy] = mvp.x;
+            out_mvp[2 * xy + 1] = mvp.y;
+        }
+    }
+    delete[] tmp;
+    delete[] mvs;
+}
+
 /* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */
 int ref_me_buf(void *h, int kind, pixel *enc, intptr_t encStride, int puOffset, int w, int hgt,
                pixel *fref, intptr_t stride)

@@ -141,6 +141,53 @@ int main(int argc, char **argv)
             printf("fieldstats %u %u %d\n", field.hits(), field.misses(), (int)field.size());
             me.attachField(NULL);
         }
+        // (7) the chained field: the device searches every 16x16 PU of the picture with the encoder's predictor chain;
+        //     then an "encoder" walks the PUs in coding order, derives each AMVP predictor from ITS OWN decisions
+        //     (template costs through mcCost, as xEstimateMvPredAMVP does) and calls motionEstimate at the unchanged
+        //     call site.  One PU (the 46th) is "coded intra" (its MV is zero for its neighbours), so the chains differ
+        //     around it and the requests that depend on it miss (and are searched on the spot); everything else is served from the field.
+        {
+            const int pu = 16, merange = 32, gw = W / pu, gh = H / pu;
+            x265amd::MotionField field(ctx);
+            me.setSearchMethod(1);
+            me.setSubpelRefine(5);
+            me.setQP(30);
+            field.runChained(pe, pr, pu, merange, 1, 5, 30);
+            me.attachField(&field);
+            std::vector<x265amd::MV> dec(gw * gh);
+            for (int gy = 0; gy < gh; gy++)
+                for (int gx = 0; gx < gw; gx++)
+                {
+                    const int xy = gx + gy * gw;
+                    me.setSourcePUxy(gx * pu, gy * pu, pu, pu);
+                    const bool haveL = gx > 0, haveA = gy > 0, haveAR = gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
+                    x265amd::MV pred[3], cand[2], b;
+                    if (haveL) pred[0] = dec[xy - 1];
+                    if (haveA) pred[1] = dec[xy - gw];
+                    if (haveAR) pred[2] = dec[xy - gw + 1];
+                    const bool haveB = haveAR || haveA || haveAL;
+                    if (haveAR) b = dec[xy - gw + 1]; else if (haveA) b = dec[xy - gw]; else if (haveAL) b = dec[xy - gw - 1];
+                    if (haveL) { cand[0] = dec[xy - 1]; if (haveB && b != cand[0]) cand[1] = b; }
+                    else if (haveB) cand[0] = b;
+                    x265amd::MV mvp = cand[0];
+                    if (cand[1] != cand[0])
+                    {
+                        x265amd::MV cl[2] = { x265amd::clipMv(cand[0], W, H, gx * pu, gy * pu), x265amd::clipMv(cand[1], W, H, gx * pu, gy * pu) };
+                        int32_t t[2];
+                        me.mcCost(X265AMD_SAD, pr, cl, 2, t);
+                        if (t[1] < t[0]) mvp = cand[1];
+                    }
+                    x265amd::MV lo, hi, out;
+                    x265amd::setSearchRange(mvp, merange, W, H, gx * pu, gy * pu, lo, hi);
+                    int cost = me.motionEstimate(&pr, lo, hi, mvp, 3, pred, merange, out);
+                    const bool intra = xy == 45;
+                    dec[xy] = intra ? x265amd::MV(0, 0) : out;
+                    printf("chain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", gx, gy, mvp.x, mvp.y, lo.x, lo.y, hi.x, hi.y,
+                           pred[0].x, pred[0].y, pred[1].x, pred[1].y, pred[2].x, pred[2].y, out.x, out.y, cost, intra ? 1 : 0);
+                }
+            printf("chainstats %u %u %d\n", field.hits(), field.misses(), gw * gh);
+            me.attachField(NULL);
+        }
         ctx.releasePlane(pe);
         ctx.releasePlane(pr);
     }

@@ -239,3 +239,26 @@ def run_ip_suite(impl, bits: int, depth: int) -> dict:
                 o = impl.ipfilter_run(kind, s, 8, 8, w, h, frac, depth)
                 out["k%d_f%d_%dx%d" % (kind, frac, w, h)] = np.ascontiguousarray(o)
     return out
+
+
+# whole-frame fields with predInterSearch's predictor chain: (pu_w, pu_h, merange, method, subme, qp, content)
+CHAIN_W, CHAIN_H = 208, 120
+CHAIN_CASES = ((16, 16, 32, J.HEX, 5, 30, "motion"), (8, 8, 16, J.DIA, 2, 22, "motion"), (32, 32, 24, J.STAR, 3, 37, "motion"),
+               (64, 64, 16, J.UMH, 1, 27, "noise"), (16, 8, 20, J.HEX, 7, 33, "noise"), (8, 8, 6, J.FULL, 0, 30, "motion"),
+               (16, 16, 64, J.STAR, 5, 32, "motion"))
+
+
+def chain_frames(bits: int, kind: str):
+    return synth.make_sequence(CHAIN_W, CHAIN_H, 2, seed=4242 + bits, bit_depth=8 if bits == 8 else 10, kind=kind)
+
+
+def run_chain_suite(impl, bits: int) -> dict:
+    """impl.field_run(enc, ref, pu_w, pu_h, merange, method, subme, qp) -> (results[gh, gw], mvp[gh, gw, 2])"""
+    out = {}
+    for k, (pw, ph, mr, method, subme, qp, kind) in enumerate(CHAIN_CASES):
+        fr = chain_frames(bits, kind)
+        res, mvp = impl.field_run(fr[1], fr[0], pw, ph, mr, method, subme, qp)
+        out["res%d" % k] = np.ascontiguousarray(res)
+        out["mvp%d" % k] = np.ascontiguousarray(mvp)
+    return out
+

@@ -124,6 +124,19 @@ class Oracle:
         ev = self.lib.meo_lookahead_me(C.byref(enc), C.byref(ref), cu_w, cu_h, merange, method, subme, qp, out.ctypes.data)
         return out, ev
 
+    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN):
+        """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain"""
+        enc = self.make_plane(enc_padded, bit_depth, margin)
+        ref = self.make_plane(ref_padded, bit_depth, margin)
+        pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
+        gw, gh = pw // pu_w, ph // pu_h
+        out = np.zeros((gh, gw), dtype=RESULT_DTYPE)
+        mvp = np.zeros((gh, gw, 2), dtype=np.int16)
+        self.lib.meo_field_me.restype = C.c_int64
+        ev = self.lib.meo_field_me(C.byref(enc), C.byref(ref), pw, ph, pu_w, pu_h, merange, method, subme, qp,
+                                   out.ctypes.data_as(C.c_void_p), mvp.ctypes.data_as(C.c_void_p))
+        return out, mvp, ev
+
     def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN, lowres=False):
         """returns (results, evals).  lowres: every entry of ref_padded_list is a list of the four
         half-resolution planes (the search then takes the isLowres branches)"""
@@ -240,6 +253,23 @@ class Reference:
         out = np.zeros(cu_w * cu_h, dtype=RESULT_DTYPE)
         out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
         return out
+
+    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, margin: int = MARGIN):
+        """(results[gh, gw], mvp[gh, gw, 2]): the reference's MotionEstimate driven over a PU grid with
+        predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me)"""
+        pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
+        gw, gh = pw // pu_w, ph // pu_h
+        mv = np.zeros((gh * gw, 2), dtype=np.int16)
+        cost = np.zeros(gh * gw, dtype=np.int32)
+        mvp = np.zeros((gh, gw, 2), dtype=np.int16)
+        assert enc_padded.shape == ref_padded.shape
+        self.lib.ref_field_me.restype = None
+        self.lib.ref_field_me.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t] + [C.c_int] * 8 + [C.c_void_p] * 3
+        self.lib.ref_field_me(self.me, plane_origin(enc_padded, margin), plane_origin(ref_padded, margin), enc_padded.shape[1],
+                              pw, ph, pu_w, pu_h, merange, method, subme, qp, mv.ctypes.data, cost.ctypes.data, mvp.ctypes.data)
+        out = np.zeros(gh * gw, dtype=RESULT_DTYPE)
+        out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
+        return out.reshape(gh, gw), mvp
 
     def search(self, enc_padded, ref_padded_list, jobs, margin: int = MARGIN, lowres=False):
         """Runs every job through MotionEstimate::motionEstimate; returns RESULT_DTYPE array.

@@ -100,3 +100,20 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
     exp, _ = oracle.search(fr[0], [fr[1]], jb)
     bp = [l for l in lines if l[0] == "bipred"][0]
     assert [int(v) for v in bp[1:]] == [int(exp["mvx"][0]), int(exp["mvy"][0]), int(exp["cost"][0])]
+    # (7) the chained field behind the unchanged call site: every request - hit or miss - returns what the oracle
+    #     computes for the arguments actually passed, and at least 90 % of the requests are served from the field
+    rows = [l for l in lines if l[0] == "chain"]
+    assert len(rows) == (W // 16) * (H // 16)
+    parts = []
+    for l in rows:
+        v = [int(t) for t in l[1:]]
+        jb = J.make_jobs(W, H, [v[0] * 16], [v[1] * 16], 16, 16, method=J.HEX, subme=5, merange=32, qp=30, qmvp=(v[2], v[3]),
+                         mvc=[[v[8], v[9]], [v[10], v[11]], [v[12], v[13]]])
+        jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = v[4], v[5], v[6], v[7]
+        parts.append(jb)
+    exp, _ = oracle.search(fr[0], [fr[1]], np.concatenate(parts), threads=4)
+    for l, ex in zip(rows, exp):
+        assert (int(l[15]), int(l[16]), int(l[17])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"])), l
+    st = [int(v) for v in [l for l in lines if l[0] == "chainstats"][0][1:]]
+    assert st[0] + st[1] == st[2] and st[0] >= 0.9 * st[2], st
+

@@ -1,0 +1,74 @@
+"""GPU parity of the whole-frame field with the encoder's predictor chain (x265amd_field_me): every PU's
+predictor, range and candidates are derived on the device from the neighbours' final MVs."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from x265_amd import jobs as J
+from x265_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from x265_amd.api import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+class GpuChain:
+    def __init__(self, eng, bits):
+        self.eng, self.depth = eng, 8 if bits == 8 else 10
+
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp):
+        ids = [self.eng.upload_plane(enc, bit_depth=self.depth), self.eng.upload_plane(ref, bit_depth=self.depth)]
+        out = self.eng.field_me(ids[0], ids[1], pw, ph, mr, method, subme, qp)
+        for i in ids:
+            self.eng.release_plane(i)
+        return out
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_match_reference_vectors(eng, bits):
+    """the fixtures made by the compiled reference's MotionEstimate under oracle/ref_shim.cpp's driver
+    (all five methods, PU sizes 8x8 .. 64x64 and 16x8, motion and noise content), replayed on the GPU"""
+    gold = np.load(os.path.join(G.GOLDEN_DIR, "chain_u%d.npz" % bits), allow_pickle=False)
+    got = G.run_chain_suite(GpuChain(eng, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+@pytest.mark.parametrize("pu,method,subme", [(16, J.HEX, 5), (64, J.STAR, 3), (8, J.HEX, 1)])
+def test_1080p_field_matches_oracle(eng, oracle, pu, method, subme):
+    """a whole 1080p frame: results, predictors and the evaluation count equal the CPU restatement's"""
+    W, H = 1920, 1080
+    fr = synth.make_sequence(W, H, 2, seed=91)
+    ids = [eng.upload_plane(f) for f in fr]
+    exp, exp_mvp, evals = oracle.field_me(fr[1], fr[0], pu, pu, 64, method, subme, 32)
+    eng.eval_count(reset=True)
+    got, got_mvp = eng.field_me(ids[1], ids[0], pu, pu, 64, method, subme, 32)
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
+    assert np.array_equal(got_mvp, exp_mvp)
+    assert eng.eval_count() == evals
+    assert (exp_mvp != 0).any(-1).mean() > 0.5         # the chain really carries predictors
+    for i in ids:
+        eng.release_plane(i)
+
+
+def test_field_rejects_bad_arguments(eng):
+    from x265_amd.api import X265AmdError
+    fr = synth.make_sequence(128, 64, 2, seed=3)
+    ids = [eng.upload_plane(f) for f in fr]
+    with pytest.raises(X265AmdError):
+        eng.field_me(ids[0], ids[1], 20, 16, 16, J.HEX, 1, 30)
+    small = synth.make_sequence(128, 64, 1, seed=3)[0][16:-16, 16:-16].copy()       # margins of 64 < 78
+    sid = eng.upload_plane(small, margin=64)
+    with pytest.raises(X265AmdError, match="-5"):
+        eng.field_me(sid, sid, 16, 16, 16, J.HEX, 1, 30)
+    for i in ids + [sid]:
+        eng.release_plane(i)

@@ -96,3 +96,24 @@ def test_bidirectional_refinement_matches_reference_vectors(oracle, bits):
     got, _ = oracle.search(mod, [rf], jobs, bit_depth=8 if bits == 8 else 10)
     bad = np.nonzero(got != gold["res"])[0]
     assert bad.size == 0, (jobs[bad[:3]], got[bad[:3]], gold["res"][bad[:3]])
+
+
+class OracleChain:
+    def __init__(self, oracle, bits):
+        self.o, self.depth = oracle, 8 if bits == 8 else 10
+
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp):
+        return self.o.field_me(enc, ref, pw, ph, mr, method, subme, qp, bit_depth=self.depth)[:2]
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_match_reference_vectors(oracle, bits):
+    """whole-frame fields searched in raster order with predictors derived from the neighbours' results
+    (AMVP choice by template SAD, xSetSearchRange, three neighbour candidates), as produced by the compiled
+    reference's MotionEstimate and primitives under oracle/ref_shim.cpp's driver"""
+    gold = _load("chain_u%d.npz" % bits)
+    got = G.run_chain_suite(OracleChain(oracle, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+

@@ -21,6 +21,9 @@ SAD, SATD, SA8D = 0, 1, 2
 PAIR_DTYPE = np.dtype([("enc_plane", "<i4"), ("enc_x", "<i4"), ("enc_y", "<i4"),
                        ("ref_plane", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4")], align=True)
 
+MC_PAIR_DTYPE = np.dtype([("enc_plane", "<i4"), ("pu_x", "<i4"), ("pu_y", "<i4"),
+                          ("ref_plane", "<i4"), ("qmv_x", "<i4"), ("qmv_y", "<i4")], align=True)
+
 PIXELCMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t)
 PIXELCMP_X3 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
 PIXELCMP_X4 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
@@ -73,6 +76,9 @@ def load_library() -> C.CDLL:
     L.x265amd_plane_geometry.argtypes = [vp, ci, cip, cip, cip, cip, C.POINTER(C.c_ssize_t), cip, cip]
     L.x265amd_ipfilter.argtypes = [vp, ci, vp, C.c_ssize_t, vp, C.c_ssize_t, ci, ci, ci, ci, ci]
     L.x265amd_lookahead_status.argtypes = [vp]
+    L.x265amd_field_me.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.x265amd_field_results_device.argtypes = [vp]
+    L.x265amd_field_results_device.restype = vp
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
     L.x265amd_plane_device_ptr.restype = vp
     L.x265amd_plane_release.argtypes = [vp, ci]
@@ -86,6 +92,7 @@ def load_library() -> C.CDLL:
     L.x265amd_lookahead_results_device.argtypes = [vp]
     L.x265amd_lookahead_results_device.restype = vp
     L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    L.x265amd_mc_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device_noalloc.argtypes = [vp, ci, cip, ci, vp, ci, vp]
@@ -258,11 +265,30 @@ class Engine:
                                                 out.ctypes.data if fetch else None))
         return out
 
+    def field_me(self, enc_plane: int, ref_plane: int, pu_w: int, pu_h: int, merange: int, method: int, subme: int, qp: int,
+                 fetch: bool = True):
+        """whole-frame field of pu_w x pu_h PUs with the neighbour-derived predictor chain; returns
+        (results[gh, gw], mvp[gh, gw, 2]) or None with fetch=False (asynchronous)"""
+        w, h = self.plane_geometry(enc_plane)[:2]
+        gw, gh = w // pu_w, h // pu_h
+        out = np.zeros((gh, gw), dtype=RESULT_DTYPE) if fetch else None
+        mvp = np.zeros((gh, gw, 2), dtype=np.int16) if fetch else None
+        self._chk(self.lib.x265amd_field_me(self.h, enc_plane, ref_plane, pu_w, pu_h, merange, method, subme, qp,
+                                            out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
+        return (out, mvp) if fetch else None
+
     # -- costs --------------------------------------------------------------------------------
     def cost_batch(self, kind: int, w: int, h: int, pairs: np.ndarray) -> np.ndarray:
         pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
         out = np.zeros(len(pairs), dtype=np.int32)
         self._chk(self.lib.x265amd_cost_batch(self.h, kind, w, h, len(pairs), pairs.ctypes.data, out.ctypes.data))
+        return out
+
+    def mc_cost_batch(self, kind: int, w: int, h: int, pairs: np.ndarray) -> np.ndarray:
+        """costs of PUs against motion-compensated (interpolated) blocks at q-pel MVs (MC_PAIR_DTYPE)"""
+        pairs = np.ascontiguousarray(pairs, dtype=MC_PAIR_DTYPE)
+        out = np.zeros(len(pairs), dtype=np.int32)
+        self._chk(self.lib.x265amd_mc_cost_batch(self.h, kind, w, h, len(pairs), pairs.ctypes.data, out.ctypes.data))
         return out
 
     # -- search -------------------------------------------------------------------------------

@@ -1,0 +1,137 @@
+// Whole-frame motion field with the predictor chain of the inter-prediction search (gfx950).
+//
+// TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2341-2455) searches the PUs of a picture
+// in coding order; each search is centred on a predictor that comes from the PU's already coded
+// neighbours: the AMVP candidate whose motion-compensated block matches the source best
+// (xEstimateMvPredAMVP / xGetTemplateCost, TEncSearch.cpp:2767-2819, 2944-2958), with the neighbours'
+// MVs as extra start candidates (m_mvPredictors, :2366-2368), inside a range clipped around the
+// predictor (xSetSearchRange, :3007-3024).  This kernel runs that chain for a uniform grid of pu_w x pu_h
+// PUs over a whole picture, in raster order, so that a caller can ask for "the field the encoder would
+// compute if every PU of this size were inter-coded with its ME result" ahead of the CU analysis.
+//
+// Per PU at grid position (gx, gy), with the final MVs of its left / above / above-right / above-left
+// neighbours:
+//   * candidate A = left MV; candidate B = the first that exists of above-right, above, above-left
+//     (the spatial AMVP scan order of HEVC); B is dropped when equal to A; the list is padded with zero
+//     vectors to AMVP_MAX_NUM_CANDS = 2 (Lib/TLibCommon/CommonDef.h:161).  No temporal candidate.
+//   * mvp = the candidate with the smaller template cost = SAD of the source PU against the
+//     motion-compensated block at the candidate clipped by TComDataCU::clipMv
+//     (Lib/TLibCommon/TComDataCU.cpp:2724-2736); xPredInterLumaBlk (TComPrediction.cpp:464-496) is the
+//     interpolation of subpelCompare.  Both index costs are one bit (xGetMvpIdxBits with num = 2), so the
+//     rate term cannot change the order; the first candidate wins a tie (`bestCost > cost`, :2803).
+//   * mvmin / mvmax = xSetSearchRange(mvp, merange) without the frame-parallel row clamp;
+//   * motionEstimate(ref, mvmin, mvmax, mvp, 3, {left, above, above-right MV or zero}, merange).
+//
+// One workgroup owns one PU row and walks it left to right; PU (gx, gy) starts when the row above has
+// finished PU gx + 1 (its last neighbour to appear), so rows form a wavefront two PUs apart - the CTU-row
+// wavefront of the reference's own encoder (encoder/frameencoder.cpp:899-930).  The hand-over between rows
+// is the one of the lookahead kernel (me_lowres.h): one 64-bit device-scope store per result into an array
+// pre-filled with an impossible MV, polled by the row below with device-scope loads; a row waits only on
+// the row dispatched just before it, and a time limit turns a lost predecessor into an error code.
+#pragma once
+
+#include "me_lowres.h"
+
+namespace xa {
+
+template <class L>
+__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, int enc_plane, int ref_plane,
+                                                 int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
+                                                 int merange, int method, int subme, int qp, int flags,
+                                                 x265amd_me_result *out, int *out_mvp, int *error, unsigned long long *evals)
+{
+    __shared__ __align__(16) L lds;
+    const int gy = (int)blockIdx.x;                                     // workgroup 0: the top row
+    if (L::NW > 1 && Dev<L>::wave_id() != 0)
+    {
+        Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
+        return;
+    }
+    const PlaneDesc &enc = planes[enc_plane];
+    const PlaneDesc &ref = planes[ref_plane];
+    unsigned n_evals = 0;
+    int failed = 0;
+    int left = 0;                                                        // MV word of the PU searched last
+    Wave<L> W;
+    W.sliced = false;
+    auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };
+
+    for (int gx = 0; gx < gw; gx++)
+    {
+        const int px = gx * pu_w, py = gy * pu_h;
+        const bool have_l = gx > 0, have_a = gy > 0, have_ar = gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
+        // (the PU is cached while the row above may still be busy)
+        W.bind(lds, enc, ref, px, py, px, py, pu_w, pu_h, cost, flags, true);
+        int w_al = 0, w_a = 0, w_ar = 0;
+        if (have_a && !failed)
+        {
+            const x265amd_me_result *above = out + (size_t)(gy - 1) * gw + gx;
+            const int v = LookLeaf::wait_mv3(above, (have_al ? 1 : 0) | 2 | (have_ar ? 4 : 0));
+            w_al = __builtin_amdgcn_readlane(v, 0);
+            w_a = __builtin_amdgcn_readlane(v, 1);
+            w_ar = __builtin_amdgcn_readlane(v, 2);
+            failed |= (w_al == LOOK_UNSET) | (w_a == LOOK_UNSET) | (w_ar == LOOK_UNSET);
+        }
+        auto mvx = [](int word) { return XA_S16(word & 0xffff); };
+        auto mvy = [](int word) { return XA_S16(word >> 16); };
+        // the two AMVP candidates
+        const int wb = have_ar ? w_ar : have_a ? w_a : w_al;
+        const bool have_b = have_a;                                     // (above exists whenever any of the three does)
+        int c0x = 0, c0y = 0, c1x = 0, c1y = 0;
+        if (have_l)
+        {
+            c0x = mvx(left); c0y = mvy(left);
+            if (have_b && wb != left)
+            {
+                c1x = mvx(wb); c1y = mvy(wb);
+            }
+        }
+        else if (have_b)
+        {
+            c0x = mvx(wb); c0y = mvy(wb);
+        }
+        // TComDataCU::clipMv for a CU at (px, py)
+        const int xmax = (pic_w + 8 - px - 1) << 2, xmin = (-max_cu - 8 - px + 1) << 2;
+        const int ymax = (pic_h + 8 - py - 1) << 2, ymin = (-max_cu - 8 - py + 1) << 2;
+        W.ikind = X265AMD_SAD;
+        int mvpx = c0x, mvpy = c0y;
+        if (c1x != c0x || c1y != c0y)
+        {
+            // xGetTemplateCost of both candidates (equal candidates cost the same and the first one stays)
+            const int t0 = W.subpel_cost(clipq(c0x, xmin, xmax), clipq(c0y, ymin, ymax), X265AMD_SAD, false);
+            const int t1 = W.subpel_cost(clipq(c1x, xmin, xmax), clipq(c1y, ymin, ymax), X265AMD_SAD, false);
+            if (t1 < t0)
+            {
+                mvpx = c1x; mvpy = c1y;
+            }
+        }
+        JobRegs j;
+        j.pu_x = px; j.pu_y = py; j.w = pu_w; j.h = pu_h;
+        // xSetSearchRange
+        const int cpx = clipq(mvpx, xmin, xmax), cpy = clipq(mvpy, ymin, ymax);
+        j.mvmin_x = XA_S16(clipq(XA_S16(cpx - (merange << 2)), xmin, xmax)) >> 2;
+        j.mvmin_y = XA_S16(clipq(XA_S16(cpy - (merange << 2)), ymin, ymax)) >> 2;
+        j.mvmax_x = XA_S16(clipq(XA_S16(cpx + (merange << 2)), xmin, xmax)) >> 2;
+        j.mvmax_y = XA_S16(clipq(XA_S16(cpy + (merange << 2)), ymin, ymax)) >> 2;
+        j.qmvp_x = mvpx; j.qmvp_y = mvpy;
+        j.merange = merange; j.method = method; j.subme = subme; j.qp = qp;
+        j.numc = 3; j.ref_idx = 0; j.icost = X265AMD_SAD;
+        j.mvc[0][0] = have_l ? mvx(left) : 0;  j.mvc[0][1] = have_l ? mvy(left) : 0;
+        j.mvc[1][0] = have_a ? mvx(w_a) : 0;   j.mvc[1][1] = have_a ? mvy(w_a) : 0;
+        j.mvc[2][0] = have_ar ? mvx(w_ar) : 0; j.mvc[2][1] = have_ar ? mvy(w_ar) : 0;
+        j.mvc[3][0] = j.mvc[3][1] = 0;
+
+        Search<L> S(W, j);
+        int ox, oy;
+        const int c = S.run(nullptr, 0, ox, oy);
+        n_evals += W.evals;
+        left = (oy << 16) | (ox & 0xffff);
+        if (out_mvp)
+            LookLeaf::store_word(out_mvp + (size_t)gy * gw + gx, (mvpy << 16) | (mvpx & 0xffff));
+        LookLeaf::publish(out + (size_t)gy * gw + gx, ox, oy, c);
+    }
+    Dev<L>::post(W.base, Dev<L>::OP_EXIT);
+    LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
+}
+
+} // namespace xa

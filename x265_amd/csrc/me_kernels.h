@@ -98,6 +98,29 @@ __global__ void __launch_bounds__(64) k_cost(const PlaneDesc *planes, int kind, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Batched costs of motion-compensated blocks: one wavefront per (PU, q-pel MV): the PU at (enc_x, enc_y)
+// against the prediction block of the same position displaced by the MV in the reference plane,
+// interpolated as TComPrediction::xPredInterLumaBlk / subpelCompare do (TComPrediction.cpp:464-496,
+// encoder/motion.cpp:1140-1165).
+template <typename PIX>
+__global__ void __launch_bounds__(64) k_mc_cost(const PlaneDesc *planes, int kind, int w, int h,
+                                                const x265amd_mc_pair *pairs, int n, int32_t *out)
+{
+    typedef JobLds<PIX, 1, 1024> L;
+    __shared__ __align__(16) L lds;
+    int id = blockIdx.x;
+    if (id >= n)
+        return;
+    const x265amd_mc_pair &p = pairs[id];
+    Wave<L> W;
+    W.bind(lds, planes[p.enc_plane], planes[p.ref_plane], p.pu_x, p.pu_y, p.pu_x, p.pu_y, w, h, nullptr,
+           JF_NO_WINDOW | JF_NO_SLICES);
+    int c = W.subpel_cost(XA_S16(p.qmv_x), XA_S16(p.qmv_y), kind, false);
+    if (threadIdx.x == 0)
+        out[id] = c;
+}
+
+// ------------------------------------------------------------------------------------------
 // The four 8-tap luma filter primitives on their own (common/primitives.h:186-188, 263-265;
 // common/ipfilter.cpp:38-139, 265-309, 354-425), through the same device functions the search's
 // prediction code uses.  kind 0 = ipfilter_pp[H_8], 1 = ipfilter_pp[V_8], 2 = ipfilter_ps[H_8]

@@ -142,6 +142,12 @@ struct LookLeaf
             __hip_atomic_store((unsigned long long*)out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // one lane stores a word
+    static __device__ __noinline__ void store_word(int *p, int v)
+    {
+        if (threadIdx.x == 0)
+            *p = v;
+    }
     static __device__ __noinline__ void finish(unsigned long long *evals, unsigned n_evals, int *error, int failed)
     {
         if (threadIdx.x == 0)

@@ -4,6 +4,7 @@
 #include "me_full.h"
 #include "me_hier.h"
 #include "me_lowres.h"
+#include "me_field.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -66,6 +67,7 @@ struct x265amd_ctx
     unsigned long long *d_evals = nullptr;   // EVAL_SLOTS counters 16 words apart (+ 16 words of developer counters)
 
     DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress;
+    DevBuf field_results, field_mvp;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
     bool   hier_ok = false;               // the MV-cost tables are small enough for the hierarchical kernel's 32-bit keys
@@ -996,7 +998,7 @@ void x265amd_destroy(x265amd_ctx *c)
         c->batch_list = nullptr;
     }
     DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs,
-                       &c->look_pairs, &c->look_results, &c->look_progress };
+                       &c->look_pairs, &c->look_results, &c->look_progress, &c->field_results, &c->field_mvp };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -1407,6 +1409,86 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
     return c ? (const x265amd_me_result*)c->look_results.p : nullptr;
 }
 
+extern "C++" {
+namespace {
+template <typename PIX>
+void launch_field(x265amd_ctx *c, int cls, int gh, const uint16_t *cost, int enc_plane, int ref_plane, int pu_w, int pu_h, int gw,
+                  int pic_w, int pic_h, int merange, int method, int subme, int qp, x265amd_me_result *res, int *mvp, int *error)
+{
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false>>), dim3(gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
+                                              enc_plane, ref_plane, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
+                                              res, mvp, error, c->d_evals)
+    if (cls == 0)      XA_FIELD(1, 64);
+    else if (cls == 1) XA_FIELD(4, 256);
+    else               XA_FIELD(8, 1024);
+#undef XA_FIELD
+}
+} // namespace
+} // extern "C++"
+
+int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method, int subme, int qp,
+                     x265amd_me_result *out, int16_t *out_mvp)
+{
+    if (!c)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int refs[1] = { ref_plane };
+    if (int rc = check_batch_planes(c, enc_plane, refs, 1)) return rc;
+    if (!valid_dim(pu_w) || !valid_dim(pu_h) || method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 ||
+        qp < 0 || qp > 51 || merange < 0 || merange > 32767 || (method == X265AMD_UMH && pu_w == 4 && pu_h == 4))
+        return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
+    const PlaneDesc &e = c->h_planes[enc_plane], &r = c->h_planes[ref_plane];
+    if (e.lr_step || r.lr_step || e.width != r.width || e.height != r.height)
+        return fail(c, X265AMD_ERR_INVALID, "field search needs two full-resolution planes of one picture size");
+    // clipMv lets a block reach 64 + 8 - 1 pixels beyond the picture; plus pattern overshoot and the filter apron
+    if (r.margin_x < 71 + 3 + 4 || r.margin_y < 71 + 3 + 4)
+        return fail(c, X265AMD_ERR_RANGE, "reference margins below 78 pixels");
+    const int gw = e.width / pu_w, gh = e.height / pu_h;
+    if (gw < 1 || gh < 1)
+        return fail(c, X265AMD_ERR_INVALID, "picture smaller than one PU");
+    const size_t n = (size_t)gw * gh;
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->field_results, n * sizeof(x265amd_me_result))) return rc;
+    if (int rc = ensure(c, c->field_mvp, n * sizeof(int))) return rc;
+    if (int rc = ensure(c, c->look_progress, sizeof(int))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->field_results.p, LOOK_UNSET, n * 2, c->stream));   // "not searched yet"
+    if (int rc = record_start(c)) return rc;
+    if (c->timing)
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
+    const int cls = job_class(pu_w, pu_h);
+    if (e.bpp == 1)
+        launch_field<uint8_t>(c, cls, gh, cost, enc_plane, ref_plane, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
+                              (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
+    else
+        launch_field<uint16_t>(c, cls, gh, cost, enc_plane, ref_plane, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
+                               (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
+    HIPCHK(c, hipGetLastError());
+    if (c->timing)
+    {
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        c->timed_any = true;
+    }
+    if (!out)
+        return 0;
+    int h_err = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->field_results.p, n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
+    if (out_mvp)
+        HIPCHK(c, hipMemcpyAsync(out_mvp, c->field_mvp.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&h_err, c->look_progress.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_err)
+        return fail(c, X265AMD_ERR_HIP, "field search: a PU row waited too long for the row above it");
+    return 0;
+}
+
+const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *c)
+{
+    return c ? (const x265amd_me_result*)c->field_results.p : nullptr;
+}
+
 int x265amd_lookahead_status(x265amd_ctx *c)
 {
     if (!c)
@@ -1498,6 +1580,50 @@ int x265amd_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x265
     else
         hipLaunchKernelGGL(k_cost<uint16_t>, dim3(n), dim3(64), 0, c->stream, c->d_planes, kind, w, h,
                            (const x265amd_block_pair*)c->pairs.p, n, (int32_t*)c->costs.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->costs.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int x265amd_mc_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x265amd_mc_pair *pairs, int32_t *out)
+{
+    if (!c || !pairs || !out || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (kind < X265AMD_SAD || kind > X265AMD_SA8D || !valid_dim(w) || !valid_dim(h))
+        return fail(c, X265AMD_ERR_INVALID, "bad cost kind or block size");
+    int bpp = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_mc_pair &p = pairs[i];
+        if (p.enc_plane < 0 || p.enc_plane >= MAX_PLANES || !c->used[p.enc_plane] ||
+            p.ref_plane < 0 || p.ref_plane >= MAX_PLANES || !c->used[p.ref_plane])
+            return fail(c, X265AMD_ERR_INVALID, "pair names an unregistered plane");
+        const PlaneDesc &e = c->h_planes[p.enc_plane], &r = c->h_planes[p.ref_plane];
+        if (e.bpp != r.bpp || (bpp && e.bpp != bpp) || r.lr_step)
+            return fail(c, X265AMD_ERR_INVALID, "mixed pixel sizes in one batch, or a half-resolution reference");
+        bpp = e.bpp;
+        if (p.qmv_x < -32768 || p.qmv_x > 32767 || p.qmv_y < -32768 || p.qmv_y > 32767)
+            return fail(c, X265AMD_ERR_INVALID, "MV does not fit 16 bits");
+        const int rx = p.pu_x + (p.qmv_x >> 2), ry = p.pu_y + (p.qmv_y >> 2);
+        if (p.pu_x < -e.margin_x || p.pu_y < -e.margin_y || p.pu_x + w > e.width + e.margin_x || p.pu_y + h > e.height + e.margin_y ||
+            rx - 3 < -r.margin_x || ry - 3 < -r.margin_y || rx + w + 4 > r.width + r.margin_x || ry + h + 4 > r.height + r.margin_y)
+            return fail(c, X265AMD_ERR_RANGE, "block (with the filter apron) outside the padded plane");
+    }
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->pairs, (size_t)n * sizeof(x265amd_mc_pair))) return rc;
+    if (int rc = ensure(c, c->costs, (size_t)n * sizeof(int32_t))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, pairs, (size_t)n * sizeof(x265amd_mc_pair), hipMemcpyHostToDevice, c->stream));
+    if (bpp == 1)
+        hipLaunchKernelGGL(k_mc_cost<uint8_t>, dim3(n), dim3(64), 0, c->stream, c->d_planes, kind, w, h,
+                           (const x265amd_mc_pair*)c->pairs.p, n, (int32_t*)c->costs.p);
+    else
+        hipLaunchKernelGGL(k_mc_cost<uint16_t>, dim3(n), dim3(64), 0, c->stream, c->d_planes, kind, w, h,
+                           (const x265amd_mc_pair*)c->pairs.p, n, (int32_t*)c->costs.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->costs.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -117,6 +117,24 @@ private:
     x265amd_ctx *m_ctx = nullptr;
 };
 
+// TComDataCU::clipMv (Lib/TLibCommon/TComDataCU.cpp:2724-2736) for a CU at (cuX, cuY) of a picW x picH picture
+// and TEncSearch::xSetSearchRange (Lib/TLibEncoder/TEncSearch.cpp:3007-3024, without the frame-parallel row
+// clamp): the two rules a call site applies between the AMVP predictor and motionEstimate().
+inline MV clipMv(MV mv, int picW, int picH, int cuX, int cuY, int maxCU = 64)
+{
+    int xmax = (picW + 8 - cuX - 1) << 2, xmin = (-maxCU - 8 - cuX + 1) << 2;
+    int ymax = (picH + 8 - cuY - 1) << 2, ymin = (-maxCU - 8 - cuY + 1) << 2;
+    int x = mv.x > xmax ? xmax : mv.x, y = mv.y > ymax ? ymax : mv.y;
+    return MV((int16_t)(x < xmin ? xmin : x), (int16_t)(y < ymin ? ymin : y));
+}
+inline void setSearchRange(MV mvp, int merange, int picW, int picH, int cuX, int cuY, MV &mvmin, MV &mvmax)
+{
+    MV c = clipMv(mvp, picW, picH, cuX, cuY);
+    int16_t d = (int16_t)(merange << 2);
+    mvmin = clipMv(MV((int16_t)(c.x - d), (int16_t)(c.y - d)), picW, picH, cuX, cuY) >> 2;
+    mvmax = clipMv(MV((int16_t)(c.x + d), (int16_t)(c.y + d)), picW, picH, cuX, cuY) >> 2;
+}
+
 // A motion field computed AHEAD of the CU analysis: the searches TEncSearch::predInterSearch is
 // expected to ask for (Lib/TLibEncoder/TEncSearch.cpp:2392-2451: one motionEstimate per PU, list and
 // reference, with a predictor the caller can often foresee, e.g. from the lookahead's half-resolution
@@ -155,6 +173,42 @@ public:
         if (!m_jobs.empty())
             m_ctx.check(x265amd_me_search_batch(m_ctx.get(), enc.plane_id, m_refs.data(), (int)m_refs.size(),
                                                 m_jobs.data(), (int)m_jobs.size(), m_results.data()));
+        m_valid = true;
+    }
+    // The whole-frame field with the encoder's own predictor chain (x265amd_field_me): every pu x pu PU of the
+    // picture searched in raster order on the device, each centred on the AMVP predictor derived from its
+    // neighbours' results.  The searches are entered into this field under the exact arguments
+    // predInterSearch would pass (predictor, xSetSearchRange bounds, the three neighbour candidates), so a
+    // call site whose neighbours carry the field's MVs - every PU coded inter with its ME result - hits.
+    void runChained(const ReferencePlanes &enc, const ReferencePlanes &ref, int pu, int merange, int method, int subme, int qp)
+    {
+        const int gw = enc.width / pu, gh = enc.height / pu;
+        std::vector<x265amd_me_result> res((size_t)gw * gh);
+        std::vector<int16_t> mvp((size_t)gw * gh * 2);
+        m_ctx.check(x265amd_field_me(m_ctx.get(), enc.plane_id, ref.plane_id, pu, pu, merange, method, subme, qp, res.data(), mvp.data()));
+        if (m_valid && m_enc != enc.plane_id)
+            clear();
+        for (int gy = 0; gy < gh; gy++)
+            for (int gx = 0; gx < gw; gx++)
+            {
+                const int xy = gx + gy * gw;
+                x265amd_me_job j = x265amd_me_job();
+                j.pu_x = gx * pu; j.pu_y = gy * pu; j.w = j.h = (int16_t)pu;
+                MV p(mvp[2 * xy], mvp[2 * xy + 1]), lo, hi;
+                setSearchRange(p, merange, enc.width, enc.height, j.pu_x, j.pu_y, lo, hi);
+                j.mvmin_x = lo.x; j.mvmin_y = lo.y; j.mvmax_x = hi.x; j.mvmax_y = hi.y;
+                j.qmvp_x = p.x; j.qmvp_y = p.y;
+                j.merange = (int16_t)merange; j.method = (uint8_t)method; j.subme = (uint8_t)subme; j.qp = (uint8_t)qp;
+                j.numc = 3; j.icost = X265AMD_SAD;
+                if (gx > 0)                { j.mvc[0][0] = res[xy - 1].mvx;      j.mvc[0][1] = res[xy - 1].mvy; }
+                if (gy > 0)                { j.mvc[1][0] = res[xy - gw].mvx;     j.mvc[1][1] = res[xy - gw].mvy; }
+                if (gy > 0 && gx + 1 < gw) { j.mvc[2][0] = res[xy - gw + 1].mvx; j.mvc[2][1] = res[xy - gw + 1].mvy; }
+                const int at = add(ref, j);
+                if ((size_t)at >= m_results.size())
+                    m_results.resize(at + 1);
+                m_results[at] = res[xy];
+            }
+        m_enc = enc.plane_id;
         m_valid = true;
     }
     // the stored result of a request identical to a planned one
@@ -230,6 +284,20 @@ public:
     int bufSAD(const ReferencePlanes &ref, int x, int y)  { return bufCost(X265AMD_SAD, ref, x, y); }
     int bufSATD(const ReferencePlanes &ref, int x, int y) { return bufCost(X265AMD_SATD, ref, x, y); }
     int bufSA8D(const ReferencePlanes &ref, int x, int y) { return bufCost(X265AMD_SA8D, ref, x, y); }
+
+    // cost of the current PU against the motion-compensated block at q-pel `mv` of `ref`: the distortion term
+    // of xGetTemplateCost (kind SAD, TEncSearch.cpp:2944-2958) and of the merge / inter-prediction error checks
+    // (kind SA8D, :2182-2190); `n` candidates in one call
+    void mcCost(int kind, const ReferencePlanes &ref, const MV *mv, int n, int32_t *out)
+    {
+        std::vector<x265amd_mc_pair> p(n);
+        for (int i = 0; i < n; i++)
+        {
+            x265amd_mc_pair q = { m_enc.plane_id, m_puX, m_puY, ref.plane_id, mv[i].x, mv[i].y };
+            p[i] = q;
+        }
+        m_ctx.check(x265amd_mc_cost_batch(m_ctx.get(), kind, m_w, m_h, n, p.data(), out));
+    }
 
     // motion.h:95 -- synchronous, one job
     int motionEstimate(const ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp,
