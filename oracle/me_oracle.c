@@ -218,3 +218,26 @@ int meo_buf_cost(const meo_plane *enc, int pu_x, int pu_y, int w, int h, int kin
     }
     return r;
 }
+
+/* cost of the cached PU against the motion-compensated block at q-pel (qx, qy): xPredInterLumaBlk + bufSAD /
+ * bufSA8D (Lib/TLibEncoder/TEncSearch.cpp:2944-2958, 2182-2190) = subpelCompare's interpolation */
+int meo_mc_cost(const meo_plane *enc, const meo_plane *ref, int pu_x, int pu_y, int w, int h, int qx, int qy, int kind)
+{
+    int r;
+    if (enc->bytes_per_px == 1)
+    {
+        state_u8 *st = (state_u8*)malloc(sizeof(state_u8));
+        bind_u8(st, enc, ref, pu_x, pu_y, w, h, 0);
+        r = subpel_cmp_u8(st, qx, qy, kind);
+        free(st);
+    }
+    else
+    {
+        state_u16 *st = (state_u16*)malloc(sizeof(state_u16));
+        bind_u16(st, enc, ref, pu_x, pu_y, w, h, 0);
+        r = subpel_cmp_u16(st, qx, qy, kind);
+        free(st);
+    }
+    return r;
+}
+

@@ -124,6 +124,9 @@ int64_t meo_search_batch(const meo_plane *enc, const meo_plane *refs, const meo_
 /* cost of cached PU against an arbitrary block (bufSAD/bufSATD/bufSA8D, motion.h:89-93) */
 int  meo_buf_cost(const meo_plane *enc, int pu_x, int pu_y, int w, int h, int kind, const void *fref, intptr_t stride);
 
+/* cost of the PU against the motion-compensated (interpolated) block at q-pel (qx, qy) of ref */
+int  meo_mc_cost(const meo_plane *enc, const meo_plane *ref, int pu_x, int pu_y, int w, int h, int qx, int qy, int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,11 @@ class Oracle:
         ev = self.lib.meo_lookahead_me(C.byref(enc), C.byref(ref), cu_w, cu_h, merange, method, subme, qp, out.ctypes.data)
         return out, ev
 
+    def mc_cost(self, enc_padded, ref_padded, pu_x, pu_y, w, h, qx, qy, kind, bit_depth=None, margin: int = MARGIN):
+        enc = self.make_plane(enc_padded, bit_depth, margin)
+        ref = self.make_plane(ref_padded, bit_depth, margin)
+        return self.lib.meo_mc_cost(C.byref(enc), C.byref(ref), pu_x, pu_y, w, h, qx, qy, kind)
+
     def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN):
         """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain"""
         enc = self.make_plane(enc_padded, bit_depth, margin)

@@ -72,3 +72,37 @@ def test_field_rejects_bad_arguments(eng):
         eng.field_me(sid, sid, 16, 16, 16, J.HEX, 1, 30)
     for i in ids + [sid]:
         eng.release_plane(i)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_mc_cost_batch_matches_oracle(eng, oracle, bits):
+    """costs against motion-compensated blocks (xGetTemplateCost's and the merge check's distortion): every
+    phase, SAD / SATD / SA8D, PU sizes of all three kernel classes, MVs reaching into the margins"""
+    from x265_amd.api import MC_PAIR_DTYPE, X265AmdError
+    depth = 8 if bits == 8 else 10
+    W, H = 256, 160
+    fr = synth.make_sequence(W, H, 2, seed=66, bit_depth=depth)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    rng = np.random.default_rng(bits)
+    for (w, h) in ((8, 8), (16, 16), (32, 16), (64, 64), (12, 16), (4, 8)):
+        n = 40
+        p = np.zeros(n, dtype=MC_PAIR_DTYPE)
+        p["enc_plane"], p["ref_plane"] = ids[0], ids[1]
+        p["pu_x"] = rng.integers(0, (W - w) // 4 + 1, n) * 4
+        p["pu_y"] = rng.integers(0, (H - h) // 4 + 1, n) * 4
+        p["qmv_x"] = rng.integers(-280, 280, n)
+        p["qmv_y"] = rng.integers(-280, 280, n)
+        p["qmv_x"][:4] = (0, 4, 2, 0)
+        p["qmv_y"][:4] = (0, 0, 0, 3)
+        for kind in (0, 1, 2):
+            got = eng.mc_cost_batch(kind, w, h, p)
+            exp = [oracle.mc_cost(fr[0], fr[1], int(q["pu_x"]), int(q["pu_y"]), w, h, int(q["qmv_x"]), int(q["qmv_y"]), kind, bit_depth=depth)
+                   for q in p]
+            assert got.tolist() == exp, (w, h, kind)
+    bad = np.zeros(1, dtype=MC_PAIR_DTYPE)
+    bad["enc_plane"], bad["ref_plane"], bad["qmv_x"] = ids[0], ids[1], -4 * 200
+    with pytest.raises(X265AmdError, match="-5"):
+        eng.mc_cost_batch(0, 16, 16, bad)
+    for i in ids:
+        eng.release_plane(i)
+
