@@ -266,6 +266,40 @@ def test_whole_cell_exhaustive_search_matches_oracle(eng, oracle, kind):
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10), (16, 12)])
+@pytest.mark.parametrize("kind", ["motion", "flat"])
+def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits, depth, kind):
+    """FULL search with the SA8D metric on every square of the 64x64 quadtree: one pass over the window
+    prices the 8x8 Hadamard cells and sums them up the tree (8- and 10-bit planes; 12-bit planes take the
+    general kernel).  Whole frames with partial cells at the edges (per-PU different clipped ranges), +-16 and
+    a non-zero predictor, a sub-pel round behind the scan, single-level lists, +-64 on one row of cells
+    (several slabs per window), rectangles mixed in, and flat pictures where only the MV cost and the
+    raster order decide."""
+    W, H = 200, 152
+    if kind == "flat":
+        a = np.full((H, W), 77 * (1 << (depth - 8)), np.int32)
+        fr = [synth.pad_plane(a, depth), synth.pad_plane(a, depth)]
+    else:
+        fr = synth.make_sequence(W, H, 2, seed=77, bit_depth=depth)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    kw = dict(method=J.FULL, icost=J.SA8D)
+    parts = [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), subme=0, merange=16, qp=27, **kw),
+             J.frame_jobs(W, H, sizes=(64, 32, 16, 8), subme=2, merange=9, qp=24, qmvp=(-37, 22), **kw),
+             J.frame_jobs(W, H, sizes=(8,), subme=0, merange=12, qp=40, qmvp=(6, 6), **kw),
+             J.frame_jobs(W, H, sizes=(32, 16), subme=0, merange=64, qp=30, **kw)[:12]]
+    x, y = J.square_pu_grid(W, H, 32)
+    parts.append(J.make_jobs(W, H, x[::3], y[::3], 32, 16, subme=0, merange=10, qp=27, **kw))
+    jobs = np.concatenate(parts)
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+    eng.eval_count(reset=True)
+    got = eng.search(ids[0], [ids[1]], jobs)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_device_resident_and_planned_paths_agree(eng, oracle):
     """The three ways in (host batch, raw device job array, planned job list) give identical,
     oracle-exact results; the job list mixes FULL jobs of every size class with pattern searches."""

@@ -1,0 +1,348 @@
+// Exhaustive (FULL_SEARCH) integer stage with the SA8D metric for all square PUs of a 64x64 picture cell
+// from one pass over the search window (8- and 16-bit pixels up to 10 bits deep).
+//
+// sa8d_inter of a square PU is built from 8x8 Hadamard sums S8 (common/pixel.cpp:276-362, 756-826):
+//   8x8           (S8 + 2) >> 2
+//   16x16         (S8a + S8b + S8c + S8d + 2) >> 2
+//   32x32, 64x64  the sum of their 16x16 values
+// so, like SAD, every square of the quadtree follows from the 8x8 cells, measured once per candidate.
+// Bundles, slabs and the partial-winner hand-over are those of me_hier.h; the work differs:
+//
+// A lane owns ONE candidate at a time and computes the whole 8x8 transform of a cell in its registers
+// on packed 16-bit pairs: the cell's 8 reference rows (two horizontally adjacent pixels per register)
+// minus the encoder rows (scalar operands, widened to 16 bits by k_pack_fenc16), three vertical
+// butterfly stages and two horizontal ones as v_pk_add_i16 / v_pk_sub_i16 (|values| <= 32 x 1023, inside
+// int16 for depths up to 10 bits), and the last horizontal stage folded into the sum of magnitudes by
+// |a + b| + |a - b| = 2 max(|a|, |b|).  No cross-lane traffic until a PU is complete; then its key
+// ((cost << 11) | candidate index inside the slab for 8x8 / 16x16, 64-bit above) is min-reduced across the wavefront.
+#pragma once
+
+#include "me_hier.h"
+
+namespace xa {
+
+constexpr int HAD_THREADS = 128;
+constexpr int HAD_WAVES = HAD_THREADS / 64;
+constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11, costs of 16x16 and below < 2^21
+constexpr int HAD_FENC_DW = 2048;         // packed encoder block: 64 cells x 8 rows x 4 dwords (8 pixels as 16-bit pairs)
+
+// Re-pack the 64x64 encoder block of every bundle as 16-bit pixels: cell z (Z-order) -> 32 consecutive
+// dwords, row r at [4 r .. 4 r + 3].
+template <typename PIX>
+__global__ void __launch_bounds__(256) k_pack_fenc16(BatchParams P, const HierBundle *bundles, int n, uint32_t *packed)
+{
+    const int b = blockIdx.x;
+    if (b >= n)
+        return;
+    const PlaneDesc &enc = P.planes[P.enc_plane];
+    const HierBundle &B = bundles[b];
+    const PIX *org = (const PIX*)enc.origin;
+    for (int i = threadIdx.x; i < HAD_FENC_DW; i += 256)
+    {
+        const int z = i >> 5, r = (i >> 2) & 7, k = i & 3;
+        int cx, cy;
+        hier_cell_xy(z, cx, cy);
+        int64_t o = (int64_t)(B.ctu_y + cy * 8 + r) * enc.stride + B.ctu_x + cx * 8 + 2 * k;
+        o = o < enc.lo ? enc.lo : (o > enc.hi - 2 ? enc.hi - 2 : o);
+        packed[(size_t)b * HAD_FENC_DW + i] = (uint32_t)org[o] | ((uint32_t)org[o + 1] << 16);
+    }
+}
+
+typedef short had_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short had_u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ had_s2 had_as_s2(uint32_t v) { had_s2 r; __builtin_memcpy(&r, &v, 4); return r; }
+
+// lo = max(a.lo, a.hi), hi = max(a.hi, a.lo)  (unsigned 16-bit)
+__device__ __forceinline__ uint32_t had_max_halves(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+
+// Sum of |8x8 Hadamard coefficients| / 2 of (ref - fenc): rows[r][c] = reference pixels (2 c, 2 c + 1) of
+// row r as 16-bit pairs, f = the cell's 32 encoder dwords in the same layout
+__device__ __forceinline__ uint32_t had8x8_half(const uint32_t (*rows)[4], const uint32_t *f)
+{
+    had_s2 a[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            a[r][c] = had_as_s2(rows[r][c]) - had_as_s2(f[4 * r + c]);
+    // vertical: three butterfly stages over the rows, two columns per instruction
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (!(r & d))
+                {
+                    const had_s2 s = a[r][c] + a[r + d][c], t = a[r][c] - a[r + d][c];
+                    a[r][c] = s;
+                    a[r + d][c] = t;
+                }
+    }
+    // horizontal: distances 4 and 2 pair whole registers; distance 1 lives inside a register and is folded
+    // into the magnitudes: |x + y| + |x - y| = 2 max(|x|, |y|)
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+        had_s2 p0 = a[r][0] + a[r][2], p2 = a[r][0] - a[r][2], p1 = a[r][1] + a[r][3], p3 = a[r][1] - a[r][3];
+        had_s2 q[4] = { p0 + p1, p0 - p1, p2 + p3, p2 - p3 };
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            const had_s2 m = __builtin_elementwise_max(q[c], -q[c]);
+            uint32_t mu;
+            __builtin_memcpy(&mu, &m, 4);
+            const uint32_t mx = had_max_halves(mu);
+            had_u2 v, one = { 1, 0 };
+            __builtin_memcpy(&v, &mx, 4);
+            sum = __builtin_amdgcn_udot2(v, one, sum, false);
+        }
+    }
+    return sum;
+}
+
+// 8 reference pixels starting at element `e` of LDS row `row` (dwords), as four 16-bit pairs
+template <typename PIX>
+__device__ __forceinline__ void had_load_row(const uint32_t *row, int e, uint32_t *out)
+{
+    if (sizeof(PIX) == 2)
+    {
+        const uint32_t *d = row + (e >> 1);
+        const uint32_t sh = (uint32_t)(e & 1) * 2;
+        uint32_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            w[k] = d[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            out[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+    }
+    else
+    {
+        const uint32_t *d = row + (e >> 2);
+        const uint32_t sh = (uint32_t)(e & 3);
+        const uint32_t w0 = d[0], w1 = d[1], w2 = d[2];
+        const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        out[0] = __builtin_amdgcn_perm(0, b0, 0x0c010c00);
+        out[1] = __builtin_amdgcn_perm(0, b0, 0x0c030c02);
+        out[2] = __builtin_amdgcn_perm(0, b1, 0x0c010c00);
+        out[3] = __builtin_amdgcn_perm(0, b1, 0x0c030c02);
+    }
+}
+
+template <typename PIX, bool MASK>
+__device__ __forceinline__ void had_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
+                                              const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
+{
+    constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
+    const int nxw = B.nxw, nyw = B.nyw, pitch = it.pitch;
+    const int y_lo = it.t_lo / nxw;                     // first candidate row of this slab = first staged window row
+
+    // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
+    uint32_t *s_win = lds;
+    uint16_t *s_cx = (uint16_t*)(s_win + it.win_rows * pitch);
+    uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
+    uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
+    unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
+    {
+        const uint8_t *r0 = (const uint8_t*)ref.origin;
+        const int64_t lo = ref.lo, hi = ref.hi - PPD;
+        const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + y_lo;
+        const int nd = it.win_nd;
+        for (int r = wv; r < it.win_rows; r += HAD_WAVES)
+            for (int c = lane; c < nd; c += 64)
+            {
+                int64_t a = (int64_t)(wy0 + r) * ref.stride + wx0 + PPD * c;
+                a = a < lo ? lo : (a > hi ? hi : a);
+                s_win[r * pitch + c] = ld_u32(r0 + a * PB);
+            }
+        const uint16_t *cost = P.cost[B.qp];
+        for (int i = tid; i < nxw; i += HAD_THREADS)
+            s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
+        for (int i = tid; i < nyw; i += HAD_THREADS)
+            s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        for (int i = tid; i < HAD_WAVES * HIER_SMALL; i += HAD_THREADS)
+            s_slot[i] = ~0u;
+        if (tid < HAD_WAVES * 5)
+            s_big[tid] = ~0ull;
+    }
+    __syncthreads();
+
+    const uint64_t cells = B.cells;
+    for (int base = it.t_lo; base < it.t_hi; base += HAD_THREADS)
+    {
+        const int task = base + tid;
+        const bool active = task < it.t_hi;
+        const int tk = active ? task : it.t_lo;
+        const int y = tk / nxw, x = tk - y * nxw;                       // candidate (x, y) of the bundle window
+        const uint32_t mv = (s_cx[x] + s_cy[y]) & 0xffffu;
+        const uint32_t *wbase = s_win + (y - y_lo) * pitch;
+
+        uint32_t q16 = 0, a32 = 0, a64 = 0;                              // raw half-sums of the running 16x16; 32x32 / 64x64 values
+        uint64_t rem = cells;
+        int z = rem ? __builtin_ctzll(rem) : 64;
+#pragma nounroll
+        while (z < 64)
+        {
+            rem &= rem - 1;
+            const int nz = rem ? __builtin_ctzll(rem) : 64;
+            int cx, cy;
+            hier_cell_xy(z, cx, cy);
+            const XA_CONST uint32_t *fe = pf + z * 32;
+            uint32_t f[32];
+#pragma unroll
+            for (int e = 0; e < 32; e++)
+                f[e] = fe[e];
+            uint32_t rows[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
+            const uint32_t h = had8x8_half(rows, f);                     // S8 / 2
+            auto kill = [&](int jid) -> bool {
+                if (!MASK)
+                    return !active;
+                const x265amd_me_job &J = jobs[jid];
+                return !active || x < J.mvmin_x - B.mvx0 || x > J.mvmax_x - B.mvx0 || y < J.mvmin_y - B.mvy0 || y > J.mvmax_y - B.mvy0;
+            };
+            const int j8 = B.job[z];
+            if (j8 >= 0)
+            {
+                const uint32_t c = ((h + 1) >> 1) + mv;                  // (S8 + 2) >> 2
+                const uint32_t k = kill(j8) ? ~0u : (c << HAD_RIDX_BITS) | (uint32_t)(tk - it.t_lo);
+                const uint32_t m = hier_wave_min_last(k);
+                if (lane == 63)
+                {
+                    uint32_t *sl = s_slot + wv * HIER_SMALL + z;
+                    *sl = m < *sl ? m : *sl;
+                }
+            }
+            q16 += h;
+            if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
+            {
+                const int q = z >> 2;
+                const uint32_t v16 = (q16 + 1) >> 1;                     // (S8a + S8b + S8c + S8d + 2) >> 2
+                q16 = 0;
+                const int j16 = B.job[64 + q];
+                if (j16 >= 0)
+                {
+                    const uint32_t k = kill(j16) ? ~0u : ((v16 + mv) << HAD_RIDX_BITS) | (uint32_t)(tk - it.t_lo);
+                    const uint32_t m = hier_wave_min_last(k);
+                    if (lane == 63)
+                    {
+                        uint32_t *sl = s_slot + wv * HIER_SMALL + 64 + q;
+                        *sl = m < *sl ? m : *sl;
+                    }
+                }
+                a32 += v16;
+                if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
+                {
+                    const int q32 = z >> 4;
+                    const int j32 = B.job[80 + q32];
+                    if (j32 >= 0)
+                    {
+                        unsigned long long m = kill(j32) ? ~0ull : ((unsigned long long)(a32 + mv) << 32) | (uint32_t)tk;
+                        m = wave_min_u64(m);
+                        if (lane == 0)
+                        {
+                            unsigned long long *sl = s_big + wv * 5 + q32;
+                            *sl = m < *sl ? m : *sl;
+                        }
+                    }
+                    a64 += a32;
+                    a32 = 0;
+                }
+            }
+            z = nz;
+        }
+        const int j64 = B.job[84];
+        if (j64 >= 0)
+        {
+            bool dead = !active;
+            if (MASK)
+            {
+                const x265amd_me_job &J = jobs[j64];
+                dead = dead || x < J.mvmin_x - B.mvx0 || x > J.mvmax_x - B.mvx0 || y < J.mvmin_y - B.mvy0 || y > J.mvmax_y - B.mvy0;
+            }
+            unsigned long long m = dead ? ~0ull : ((unsigned long long)(a64 + mv) << 32) | (uint32_t)tk;
+            m = wave_min_u64(m);
+            if (lane == 0)
+            {
+                unsigned long long *sl = s_big + wv * 5 + 4;
+                *sl = m < *sl ? m : *sl;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (tid < HIER_PUS)
+    {
+        const int jid = B.job[tid];
+        if (jid >= 0)
+        {
+            FullBest f;
+            int cost = 0x7fffffff, ridx = -1;
+            if (tid < HIER_SMALL)
+            {
+                uint32_t m = ~0u;
+                for (int w = 0; w < HAD_WAVES; w++)
+                {
+                    const uint32_t v = s_slot[w * HIER_SMALL + tid];
+                    m = v < m ? v : m;
+                }
+                if (m != ~0u)
+                {
+                    cost = (int)(m >> HAD_RIDX_BITS);
+                    ridx = it.t_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1));
+                }
+            }
+            else
+            {
+                unsigned long long m = ~0ull;
+                for (int w = 0; w < HAD_WAVES; w++)
+                {
+                    const unsigned long long v = s_big[w * 5 + (tid - HIER_SMALL)];
+                    m = v < m ? v : m;
+                }
+                if (m != ~0ull)
+                {
+                    cost = (int)(m >> 32);
+                    ridx = (int)(m & 0xffffffffu);
+                }
+            }
+            f.cost = cost;
+            f.mvx = ridx < 0 ? 0 : (int16_t)(B.mvx0 + ridx % nxw);
+            f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
+            fb[(size_t)jid * fb_stride + it.slot] = f;
+        }
+    }
+}
+
+template <typename PIX>
+__global__ void __launch_bounds__(HAD_THREADS) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+                                                          const HierItem *items, int n_items, const uint32_t *packed,
+                                                          FullBest *fb, int fb_stride)
+{
+    extern __shared__ uint32_t lds[];
+    const int id = blockIdx.x;
+    if (id >= n_items)
+        return;
+    const HierItem &it = items[id];
+    const HierBundle &B = bundles[it.bundle];
+    const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HAD_FENC_DW);
+    if (B.uniform)
+        had_item_body<PIX, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    else
+        had_item_body<PIX, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+}
+
+} // namespace xa

@@ -17,6 +17,8 @@ struct BatchParams
     int32_t          n_refs;
     int32_t          flags;               // JF_* bits applied to every job (tuning aids)
     unsigned        *hist;                // optional: evaluations spent on job i, written to hist[i]
+    const unsigned char *fb_jobs;         // optional: fb_jobs[i] != 0 = an exhaustive kernel ran job i's integer stage
+                                          // (without it: exactly the jobs full_kernel_eligible accepts)
 };
 
 // Does the dedicated exhaustive kernel handle this job?  (SAD metric, bounded range)
@@ -25,6 +27,16 @@ __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
 {
     int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     return (j.method == X265AMD_FULL || j.method == X265AMD_BIPRED) && j.icost == X265AMD_SAD && (bpp == 1 || bpp == 2) &&
+           nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
+}
+
+// Can the Hadamard exhaustive kernel (me_had.h) take this job?  (SA8D metric, bounded range; the caller
+// also checks that the PU is a square of a 64x64 cell's quadtree and that the planes are at most 10 bits deep)
+template <class J>
+__device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
+{
+    int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+    return j.method == X265AMD_FULL && j.icost == X265AMD_SA8D && (bpp == 1 || bpp == 2) &&
            nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
 }
 
@@ -64,7 +76,8 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
     W.stamp(1);
     Search<L> S(W, j);
     int ox, oy;
-    const FullBest *f = (fb && full_kernel_eligible(j, (int)sizeof(typename L::PIX))) ? fb + (size_t)id * fb_stride : nullptr;
+    const bool covered = P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(typename L::PIX));
+    const FullBest *f = (fb && covered) ? fb + (size_t)id * fb_stride : nullptr;
     int cost = S.run(f, fb_stride, ox, oy);
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     // (evaluation counts go to one of EVAL_SLOTS counters, 128 bytes apart, to spread the atomics)

@@ -3,6 +3,7 @@
 #include "me_kernels.h"
 #include "me_full.h"
 #include "me_hier.h"
+#include "me_had.h"
 #include "me_lowres.h"
 #include "me_field.h"
 
@@ -97,6 +98,9 @@ struct x265amd_joblist
     DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
     DevBuf  hier_bundles, hier_items, hier_fenc;      // whole-cell bundles of the hierarchical exhaustive kernel
     int     n_hier_bundles = 0, n_hier_items = 0, hier_lds_bytes = 0;
+    DevBuf  had_bundles, had_items, had_fenc;         // the same for the Hadamard exhaustive kernel
+    int     n_had_bundles = 0, n_had_items = 0, had_lds_bytes = 0;
+    DevBuf  fb_jobs;                      // with Hadamard bundles: one flag per job, "an exhaustive kernel covers its integer stage"
     bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
@@ -522,11 +526,15 @@ void xcd_interleave(std::vector<T> &v)
 // picture cell and that share reference, QP and predictor.  A bundle is used when measuring its 8x8
 // cells once is clearly less work than scanning every job on its own; its candidate rows are cut into
 // slabs of about one lane task (4 candidates x HIER_R rows) per thread.
-void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in_bundle,
+//
+// had = true plans the same bundles for the Hadamard kernel (me_had.h): FULL-search SA8D jobs on 8- or 16-bit
+// planes up to 10 bits deep.  There a lane task is ONE candidate, a bundle may hold a single job (the
+// general kernel's scan is far slower), and a slab has at most 2^HAD_RIDX_BITS candidates.
+void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector<char> &in_bundle,
                std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes)
 {
     lds_bytes = 0;
-    if (bpp != 1)
+    if (!had && bpp != 1)
         return;
     auto fl = [](int v) { return v >= 0 ? v / 64 : -((-v + 63) / 64); };
     auto zidx = [](int cx, int cy) {
@@ -535,7 +543,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in
     for (int i = 0; i < n; i++)
     {
         const x265amd_me_job &j = jobs[i];
-        if (!full_kernel_eligible(j, bpp) || j.w != j.h || (j.w != 8 && j.w != 16 && j.w != 32 && j.w != 64))
+        if (!(had ? had_kernel_eligible(j, bpp) : full_kernel_eligible(j, bpp)) || in_bundle[i] ||
+            j.w != j.h || (j.w != 8 && j.w != 16 && j.w != 32 && j.w != 64))
             continue;
         const int gx = fl(j.pu_x), gy = fl(j.pu_y);
         if ((j.pu_x - gx * 64) % j.w || (j.pu_y - gy * 64) % j.h)
@@ -568,13 +577,13 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in
             x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
             old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1);
         }
-        if (taken.size() < 2)
+        if (taken.size() < (had ? 1u : 2u))
             continue;
         const int nxw = x1 - x0 + 1, nyw = y1 - y0 + 1;
         if ((int64_t)nxw * nyw > (1 << HIER_RIDX_BITS))
             continue;
         const double hier_work = (double)__builtin_popcountll(B.cells) * 64.0 * nxw * nyw;
-        if (hier_work * 1.25 > old_work)
+        if (!had && hier_work * 1.25 > old_work)
             continue;
         B.uniform = 1;
         for (int i : taken)
@@ -585,11 +594,16 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in
         B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
         // slabs of about one lane task per thread
-        const int XG = (nxw + 3) >> 2, nd = XG + 16;
+        const int ppd = 4 / bpp;
+        const int XG = had ? nxw : (nxw + 3) >> 2;                              // lane tasks per task row
+        const int RT = had ? 1 : HIER_R;                                        // candidate rows per task row
+        const int nd = had ? (nxw + 67 + ppd - 1) / ppd + 1 : XG + 16;          // (the widest row read of had_load_row ends 11 pixels behind its first)
         int pitch = nd, best = 64;
         for (int p = nd; p < nd + 32; p++)
         {
-            const int d = ((HIER_R * p - XG) % 32 + 32) % 32, dd = std::min(d, 32 - d);
+            // consecutive task rows of one wavefront continue the bank sequence of the row before
+            const int step = had ? (nxw + ppd - 1) / ppd : XG;
+            const int d = ((RT * p - step) % 32 + 32) % 32, dd = std::min(d, 32 - d);
             if (dd < best)
             {
                 best = dd;
@@ -597,10 +611,13 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in
             }
         }
         // slabs of one lane task per thread (more per thread only when that would exceed the FullBest slots)
-        const int nquads = (nyw + HIER_R - 1) / HIER_R, ntasks = nquads * XG;
-        int per = HIER_THREADS;
+        const int nquads = (nyw + RT - 1) / RT, ntasks = nquads * XG;
+        const int threads = had ? HAD_THREADS : HIER_THREADS;
+        int per = threads;
         while ((ntasks + per - 1) / per > FB_STRIDE_PLAN)
-            per += HIER_THREADS;
+            per += threads;
+        if (had && per > (1 << HAD_RIDX_BITS))
+            continue;
         const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * HIER_WAVES * HIER_SMALL + 8 * HIER_WAVES * 5 + 64;
         bool fits = true;
         std::vector<HierItem> mine;
@@ -614,7 +631,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, std::vector<char> &in
             it.slot = slot;
             it.pitch = pitch;
             it.win_nd = nd;
-            it.win_rows = ((it.t_hi - 1) / XG - it.t_lo / XG + 1) * HIER_R + 63;
+            it.win_rows = ((it.t_hi - 1) / XG - it.t_lo / XG + 1) * RT + 63;
             const int bytes = 4 * it.win_rows * pitch + fixed;
             fits = fits && bytes <= FULL_LDS_MAX;
             lds_bytes = std::max(lds_bytes, bytes);
@@ -673,7 +690,30 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     std::vector<HierItem> hitems;
     L->n_hier_bundles = L->n_hier_items = L->hier_lds_bytes = 0;
     if (c->hier_ok && !(c->flags & 16)) // (tuning aid: X265AMD_FLAGS bit 4 switches the hierarchical kernel off)
-        plan_hier(jobs, n, bpp, in_bundle, hbundles, hitems, L->hier_lds_bytes);
+        plan_hier(jobs, n, bpp, false, in_bundle, hbundles, hitems, L->hier_lds_bytes);
+    std::vector<HierBundle> dbundles;
+    std::vector<HierItem> ditems;
+    L->n_had_bundles = L->n_had_items = L->had_lds_bytes = 0;
+    if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the Hadamard kernel off)
+        plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes);
+    if (!ditems.empty())
+    {
+        xcd_interleave(ditems);
+        L->n_had_bundles = (int)dbundles.size();
+        L->n_had_items = (int)ditems.size();
+        if (int rc = ensure(c, L->had_bundles, dbundles.size() * sizeof(HierBundle))) return rc;
+        if (int rc = ensure(c, L->had_items, ditems.size() * sizeof(HierItem))) return rc;
+        if (int rc = ensure(c, L->had_fenc, dbundles.size() * (size_t)HAD_FENC_DW * 4)) return rc;
+        if (int rc = ensure(c, L->fb_jobs, (size_t)n)) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->had_bundles.p, dbundles.data(), dbundles.size() * sizeof(HierBundle), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L->had_items.p, ditems.data(), ditems.size() * sizeof(HierItem), hipMemcpyHostToDevice, c->stream));
+        // (every SAD job the exhaustive kernels accept is planned below; of the SA8D jobs, those bundled here)
+        std::vector<unsigned char> flags(n);
+        for (int i = 0; i < n; i++)
+            flags[i] = full_kernel_eligible(jobs[i], bpp) || in_bundle[i];
+        HIPCHK(c, hipMemcpyAsync(L->fb_jobs.p, flags.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // flags dies here
+    }
     if (!hitems.empty())
     {
         // picture order, dealt to the XCDs in contiguous bands (bundles were made in (row, column) order)
@@ -706,7 +746,7 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         for (auto &g : groups)
             plan_group(jobs, bpp, g.second, planned);
     }
-    L->has_fb = !planned.empty() || !hitems.empty();
+    L->has_fb = !planned.empty() || !hitems.empty() || !ditems.empty();
     if (L->has_fb)
     {
         std::vector<FullBest> fb((size_t)n * FB_STRIDE_PLAN);
@@ -768,17 +808,29 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
-                       &L->hier_bundles, &L->hier_items, &L->hier_fenc };
+                       &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->fb_jobs };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
     delete L;
 }
 
+// The Hadamard kernel works on packed 16-bit differences: usable while every plane of the run is at most 10 bits deep
+bool had_usable(x265amd_ctx *c, const x265amd_joblist *L, const BatchParams &P)
+{
+    if (!L->n_had_items || c->h_planes[P.enc_plane].depth > 10)
+        return false;
+    for (int r = 0; r < P.n_refs; r++)
+        if (c->h_planes[P.ref_planes[r]].depth > 10)
+            return false;
+    return true;
+}
+
 // the exhaustive-kernel launches of a planned list
 int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
-    const int lanes = (int)std::min<size_t>(L->launches.size() + (L->n_hier_items ? 1 : 0), c->n_lanes);
+    const bool had = had_usable(c, L, P);
+    const int lanes = (int)std::min<size_t>(L->launches.size() + (L->n_hier_items ? 1 : 0) + (had ? 1 : 0), c->n_lanes);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     int k = 0;
@@ -791,6 +843,20 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
                            (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->hier_bundles.p,
                            (const HierItem*)L->hier_items.p, L->n_hier_items, (const uint32_t*)L->hier_fenc.p,
                            (FullBest*)L->fb.p, FB_STRIDE_PLAN);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (had)
+    {
+        hipStream_t st = c->lane(k++);
+#define XA_LAUNCH_HAD(PIX)                                                                                         \
+        hipLaunchKernelGGL(k_pack_fenc16<PIX>, dim3(L->n_had_bundles), dim3(256), 0, st, P,                        \
+                           (const HierBundle*)L->had_bundles.p, L->n_had_bundles, (uint32_t*)L->had_fenc.p);       \
+        hipLaunchKernelGGL(k_full_had<PIX>, dim3(L->n_had_items), dim3(HAD_THREADS), L->had_lds_bytes, st, P,      \
+                           (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,                  \
+                           (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,        \
+                           (FullBest*)L->fb.p, FB_STRIDE_PLAN)
+        if (L->bpp == 1) { XA_LAUNCH_HAD(uint8_t); } else { XA_LAUNCH_HAD(uint16_t); }
+#undef XA_LAUNCH_HAD
         HIPCHK(c, hipGetLastError());
     }
     for (const x265amd_joblist::Launch &la : L->launches)
@@ -828,6 +894,7 @@ int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams 
 {
     BatchParams P = P0;
     P.hist = L->keep_hist ? (unsigned*)L->hist.p : nullptr;
+    P.fb_jobs = had_usable(c, L, P) ? (const unsigned char*)L->fb_jobs.p : nullptr;
     L->ran = true;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
