@@ -289,6 +289,11 @@ def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits,
              J.frame_jobs(W, H, sizes=(32, 16), subme=0, merange=64, qp=30, **kw)[:12]]
     x, y = J.square_pu_grid(W, H, 32)
     parts.append(J.make_jobs(W, H, x[::3], y[::3], 32, 16, subme=0, merange=10, qp=27, **kw))
+    # the SAD metric through the same pass (16-bit planes): all levels, single small / large levels, bidirectional refinement
+    parts += [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=33, qmvp=(5, -9)),
+              J.frame_jobs(W, H, sizes=(8,), method=J.FULL, subme=1, merange=16, qp=22),
+              J.frame_jobs(W, H, sizes=(32,), method=J.FULL, subme=0, merange=16, qp=22, qmvp=(1, 1)),
+              J.frame_jobs(W, H, sizes=(32, 16), method=J.BIPRED, subme=0, merange=4, qp=30, qmvp=(3, -5))]
     jobs = np.concatenate(parts)
     exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
     eng.eval_count(reset=True)

@@ -1,5 +1,7 @@
 // Exhaustive (FULL_SEARCH) integer stage with the SA8D metric for all square PUs of a 64x64 picture cell
-// from one pass over the search window (8- and 16-bit pixels up to 10 bits deep).
+// from one pass over the search window (8- and 16-bit pixels up to 10 bits deep), and the same pass with
+// the SAD metric for 16-bit planes up to 12 bits deep (v_sad_u16 on the same packed pairs; 8-bit SAD has
+// the quad-SAD kernel of me_hier.h).
 //
 // sa8d_inter of a square PU is built from 8x8 Hadamard sums S8 (common/pixel.cpp:276-362, 756-826):
 //   8x8           (S8 + 2) >> 2
@@ -21,9 +23,10 @@
 
 namespace xa {
 
-constexpr int HAD_THREADS = 128;
-constexpr int HAD_WAVES = HAD_THREADS / 64;
-constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11, costs of 16x16 and below < 2^21
+constexpr int HAD_THREADS = 128;          // workgroup size of a launch whose windows are small; HAD_THREADS_BIG when they are
+constexpr int HAD_THREADS_BIG = 512;      // large (the wavefronts that share a staged window decide how many fit a CU)
+constexpr int HAD_WAVES = HAD_THREADS_BIG / 64;   // slot rows in LDS
+constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11 (a slab has at most 2^11 candidates), costs of 16x16 and below < 2^21
 constexpr int HAD_FENC_DW = 2048;         // packed encoder block: 64 cells x 8 rows x 4 dwords (8 pixels as 16-bit pairs)
 
 // Re-pack the 64x64 encoder block of every bundle as 16-bit pixels: cell z (Z-order) -> 32 consecutive
@@ -138,15 +141,47 @@ __device__ __forceinline__ void had_load_row(const uint32_t *row, int e, uint32_
     }
 }
 
-template <typename PIX, bool MASK>
+// SAD variant (16-bit planes): a lane owns TWO horizontally adjacent candidates (x even, x + 1), which share the
+// five dwords of every window row: the even one reads them as they are, the odd one shifted by one pixel.
+// v_sad_u16 adds both halves' differences.
+__device__ __forceinline__ void sad8x8_pair_u16(const uint32_t *wbase, int pitch, int e, const uint32_t *f, uint32_t *h)
+{
+    uint32_t s0 = 0, s1 = 0;
+    const uint32_t *d = wbase + (e >> 1);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+        uint32_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            w[k] = d[r * pitch + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            s0 = __builtin_amdgcn_sad_u16(w[k], f[4 * r + k], s0);
+            s1 = __builtin_amdgcn_sad_u16(__builtin_amdgcn_alignbyte(w[k + 1], w[k], 2), f[4 * r + k], s1);
+        }
+    }
+    h[0] = s0;
+    h[1] = s1;
+}
+
+// candidates per lane task: 2 for the SAD variant, 1 for SA8D
+__device__ __host__ constexpr int had_nc(bool sad) { return sad ? 2 : 1; }
+
+template <typename PIX, bool MASK, bool SAD>
 __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
                                               const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
 {
-    constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB;
+    constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB, NC = had_nc(SAD);
+    static_assert(!SAD || PB == 2, "the SAD variant is for 16-bit planes");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
     const int nxw = B.nxw, nyw = B.nyw, pitch = it.pitch;
-    const int y_lo = it.t_lo / nxw;                     // first candidate row of this slab = first staged window row
+    const int XP = (nxw + NC - 1) / NC;                 // lane tasks per candidate row
+    const int y_lo = it.t_lo / XP;                      // first candidate row of this slab = first staged window row
+    const int x_lo = NC * (it.t_lo - y_lo * XP);        // slab-local candidate index = (y - y_lo) * nxw + x - x_lo
 
     // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
     uint32_t *s_win = lds;
@@ -159,7 +194,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         const int64_t lo = ref.lo, hi = ref.hi - PPD;
         const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + y_lo;
         const int nd = it.win_nd;
-        for (int r = wv; r < it.win_rows; r += HAD_WAVES)
+        for (int r = wv; r < it.win_rows; r += nwaves)
             for (int c = lane; c < nd; c += 64)
             {
                 int64_t a = (int64_t)(wy0 + r) * ref.stride + wx0 + PPD * c;
@@ -167,11 +202,11 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 s_win[r * pitch + c] = ld_u32(r0 + a * PB);
             }
         const uint16_t *cost = P.cost[B.qp];
-        for (int i = tid; i < nxw; i += HAD_THREADS)
+        for (int i = tid; i < nxw; i += nthreads)
             s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
-        for (int i = tid; i < nyw; i += HAD_THREADS)
+        for (int i = tid; i < nyw; i += nthreads)
             s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
-        for (int i = tid; i < HAD_WAVES * HIER_SMALL; i += HAD_THREADS)
+        for (int i = tid; i < HAD_WAVES * HIER_SMALL; i += nthreads)
             s_slot[i] = ~0u;
         if (tid < HAD_WAVES * 5)
             s_big[tid] = ~0ull;
@@ -179,16 +214,56 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     __syncthreads();
 
     const uint64_t cells = B.cells;
-    for (int base = it.t_lo; base < it.t_hi; base += HAD_THREADS)
+    for (int base = it.t_lo; base < it.t_hi; base += nthreads)
     {
         const int task = base + tid;
         const bool active = task < it.t_hi;
         const int tk = active ? task : it.t_lo;
-        const int y = tk / nxw, x = tk - y * nxw;                       // candidate (x, y) of the bundle window
-        const uint32_t mv = (s_cx[x] + s_cy[y]) & 0xffffu;
+        const int y = tk / XP, x = NC * (tk - y * XP);                  // the task's first candidate (x, y) of the bundle window
+        uint32_t mv[NC];
+        bool valid[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+        {
+            valid[c] = active && x + c < nxw;
+            mv[c] = (s_cx[x + c < nxw ? x + c : nxw - 1] + s_cy[y]) & 0xffffu;
+        }
+        const uint32_t lidx = (uint32_t)((y - y_lo) * nxw + x - x_lo);  // slab-local index of candidate 0
+        const uint32_t ridx = (uint32_t)(y * nxw + x);                  // its raster index in the window
         const uint32_t *wbase = s_win + (y - y_lo) * pitch;
 
-        uint32_t q16 = 0, a32 = 0, a64 = 0;                              // raw half-sums of the running 16x16; 32x32 / 64x64 values
+        // raw sums of the running 16x16 (SAD, or half Hadamard sums); values of the running 32x32 / 64x64
+        uint32_t q16[NC], a32[NC], a64[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            q16[c] = a32[c] = a64[c] = 0;
+        // is candidate c outside job jid's own range?
+        auto kill = [&](int jid, int c) -> bool {
+            if (!MASK)
+                return !valid[c];
+            const x265amd_me_job &J = jobs[jid];
+            return !valid[c] || x + c < J.mvmin_x - B.mvx0 || x + c > J.mvmax_x - B.mvx0 || y < J.mvmin_y - B.mvy0 || y > J.mvmax_y - B.mvy0;
+        };
+        auto key32 = [&](int jid, const uint32_t *v) -> uint32_t {
+            uint32_t k = ~0u;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+            {
+                const uint32_t kc = kill(jid, c) ? ~0u : ((v[c] + mv[c]) << HAD_RIDX_BITS) | (lidx + c);
+                k = kc < k ? kc : k;
+            }
+            return k;
+        };
+        auto key64 = [&](int jid, const uint32_t *v) -> unsigned long long {
+            unsigned long long k = ~0ull;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+            {
+                const unsigned long long kc = kill(jid, c) ? ~0ull : ((unsigned long long)(v[c] + mv[c]) << 32) | (ridx + c);
+                k = kc < k ? kc : k;
+            }
+            return k;
+        };
         uint64_t rem = cells;
         int z = rem ? __builtin_ctzll(rem) : 64;
 #pragma nounroll
@@ -203,63 +278,76 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
 #pragma unroll
             for (int e = 0; e < 32; e++)
                 f[e] = fe[e];
-            uint32_t rows[8][4];
+            uint32_t h[NC];                                              // the cell's SAD, or S8 / 2
+            if constexpr (SAD)
+                sad8x8_pair_u16(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, h);
+            else
+            {
+                uint32_t rows[8][4];
 #pragma unroll
-            for (int r = 0; r < 8; r++)
-                had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
-            const uint32_t h = had8x8_half(rows, f);                     // S8 / 2
-            auto kill = [&](int jid) -> bool {
-                if (!MASK)
-                    return !active;
-                const x265amd_me_job &J = jobs[jid];
-                return !active || x < J.mvmin_x - B.mvx0 || x > J.mvmax_x - B.mvx0 || y < J.mvmin_y - B.mvy0 || y > J.mvmax_y - B.mvy0;
-            };
+                for (int r = 0; r < 8; r++)
+                    had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
+                h[0] = had8x8_half(rows, f);
+            }
             const int j8 = B.job[z];
             if (j8 >= 0)
             {
-                const uint32_t c = ((h + 1) >> 1) + mv;                  // (S8 + 2) >> 2
-                const uint32_t k = kill(j8) ? ~0u : (c << HAD_RIDX_BITS) | (uint32_t)(tk - it.t_lo);
-                const uint32_t m = hier_wave_min_last(k);
+                uint32_t v[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    v[c] = SAD ? h[c] : (h[c] + 1) >> 1;                 // (S8 + 2) >> 2
+                const uint32_t m = hier_wave_min_last(key32(j8, v));
                 if (lane == 63)
                 {
                     uint32_t *sl = s_slot + wv * HIER_SMALL + z;
                     *sl = m < *sl ? m : *sl;
                 }
             }
-            q16 += h;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                q16[c] += h[c];
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
                 const int q = z >> 2;
-                const uint32_t v16 = (q16 + 1) >> 1;                     // (S8a + S8b + S8c + S8d + 2) >> 2
-                q16 = 0;
+                uint32_t v16[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                {
+                    v16[c] = SAD ? q16[c] : (q16[c] + 1) >> 1;           // (S8a + S8b + S8c + S8d + 2) >> 2
+                    q16[c] = 0;
+                }
                 const int j16 = B.job[64 + q];
                 if (j16 >= 0)
                 {
-                    const uint32_t k = kill(j16) ? ~0u : ((v16 + mv) << HAD_RIDX_BITS) | (uint32_t)(tk - it.t_lo);
-                    const uint32_t m = hier_wave_min_last(k);
+                    const uint32_t m = hier_wave_min_last(key32(j16, v16));
                     if (lane == 63)
                     {
                         uint32_t *sl = s_slot + wv * HIER_SMALL + 64 + q;
                         *sl = m < *sl ? m : *sl;
                     }
                 }
-                a32 += v16;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    a32[c] += v16[c];
                 if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
                 {
                     const int q32 = z >> 4;
                     const int j32 = B.job[80 + q32];
                     if (j32 >= 0)
                     {
-                        unsigned long long m = kill(j32) ? ~0ull : ((unsigned long long)(a32 + mv) << 32) | (uint32_t)tk;
-                        m = wave_min_u64(m);
+                        const unsigned long long m = wave_min_u64(key64(j32, a32));
                         if (lane == 0)
                         {
                             unsigned long long *sl = s_big + wv * 5 + q32;
                             *sl = m < *sl ? m : *sl;
                         }
                     }
-                    a64 += a32;
-                    a32 = 0;
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                    {
+                        a64[c] += a32[c];
+                        a32[c] = 0;
+                    }
                 }
             }
             z = nz;
@@ -267,14 +355,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         const int j64 = B.job[84];
         if (j64 >= 0)
         {
-            bool dead = !active;
-            if (MASK)
-            {
-                const x265amd_me_job &J = jobs[j64];
-                dead = dead || x < J.mvmin_x - B.mvx0 || x > J.mvmax_x - B.mvx0 || y < J.mvmin_y - B.mvy0 || y > J.mvmax_y - B.mvy0;
-            }
-            unsigned long long m = dead ? ~0ull : ((unsigned long long)(a64 + mv) << 32) | (uint32_t)tk;
-            m = wave_min_u64(m);
+            const unsigned long long m = wave_min_u64(key64(j64, a64));
             if (lane == 0)
             {
                 unsigned long long *sl = s_big + wv * 5 + 4;
@@ -294,7 +375,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             if (tid < HIER_SMALL)
             {
                 uint32_t m = ~0u;
-                for (int w = 0; w < HAD_WAVES; w++)
+                for (int w = 0; w < nwaves; w++)
                 {
                     const uint32_t v = s_slot[w * HIER_SMALL + tid];
                     m = v < m ? v : m;
@@ -302,13 +383,13 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 if (m != ~0u)
                 {
                     cost = (int)(m >> HAD_RIDX_BITS);
-                    ridx = it.t_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1));
+                    ridx = y_lo * nxw + x_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1));
                 }
             }
             else
             {
                 unsigned long long m = ~0ull;
-                for (int w = 0; w < HAD_WAVES; w++)
+                for (int w = 0; w < nwaves; w++)
                 {
                     const unsigned long long v = s_big[w * 5 + (tid - HIER_SMALL)];
                     m = v < m ? v : m;
@@ -328,7 +409,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
 }
 
 template <typename PIX>
-__global__ void __launch_bounds__(HAD_THREADS) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+__global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                           const HierItem *items, int n_items, const uint32_t *packed,
                                                           FullBest *fb, int fb_stride)
 {
@@ -339,10 +420,20 @@ __global__ void __launch_bounds__(HAD_THREADS) k_full_had(BatchParams P, const x
     const HierItem &it = items[id];
     const HierBundle &B = bundles[it.bundle];
     const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HAD_FENC_DW);
-    if (B.uniform)
-        had_item_body<PIX, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    if (B.metric == X265AMD_SAD)
+    {
+        if constexpr (sizeof(PIX) == 2)
+        {
+            if (B.uniform)
+                had_item_body<PIX, false, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+            else
+                had_item_body<PIX, true, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        }
+    }
+    else if (B.uniform)
+        had_item_body<PIX, false, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else
-        had_item_body<PIX, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        had_item_body<PIX, true, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
 }
 
 } // namespace xa

@@ -52,7 +52,7 @@ struct HierBundle
     int32_t  qmvp_x, qmvp_y;    // the jobs' common predictor (q-pel) and QP
     int32_t  qp, ref_idx;
     int32_t  uniform;           // every job's range equals the window (no per-job masking)
-    int32_t  pad;
+    int32_t  metric;            // X265AMD_SAD / X265AMD_SA8D: the jobs' integer-stage metric (me_had.h; me_hier.h is SAD only)
     uint64_t cells;             // bit z: 8x8 cell z (Z-order) is covered by some job
     int32_t  job[HIER_PUS];     // job of square k (0..63: 8x8 in Z-order, 64..79: 16x16, 80..83: 32x32, 84: 64x64), -1: none
     int32_t  pad2;

@@ -30,14 +30,18 @@ __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
            nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
 }
 
-// Can the Hadamard exhaustive kernel (me_had.h) take this job?  (SA8D metric, bounded range; the caller
-// also checks that the PU is a square of a 64x64 cell's quadtree and that the planes are at most 10 bits deep)
+// Can the candidate-per-lane exhaustive kernel (me_had.h) take this job?  SA8D metric on any plane, or SAD
+// on 16-bit planes; bounded range.  (The caller also checks that the PU is a square of a 64x64 cell's
+// quadtree and, at launch, the planes' bit depth: at most 10 for SA8D, 12 for SAD.)
 template <class J>
 __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
 {
     int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
-    return j.method == X265AMD_FULL && j.icost == X265AMD_SA8D && (bpp == 1 || bpp == 2) &&
-           nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
+    if (nx <= 0 || ny <= 0 || nx > FULL_MAX_CAND || ny > FULL_MAX_CAND || (bpp != 1 && bpp != 2))
+        return false;
+    if (j.icost == X265AMD_SA8D)
+        return j.method == X265AMD_FULL;
+    return bpp == 2 && full_kernel_eligible(j, bpp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ struct x265amd_joblist
     DevBuf  hier_bundles, hier_items, hier_fenc;      // whole-cell bundles of the hierarchical exhaustive kernel
     int     n_hier_bundles = 0, n_hier_items = 0, hier_lds_bytes = 0;
     DevBuf  had_bundles, had_items, had_fenc;         // the same for the Hadamard exhaustive kernel
-    int     n_had_bundles = 0, n_had_items = 0, had_lds_bytes = 0;
+    int     n_had_bundles = 0, n_had_items = 0, had_lds_bytes = 0, had_max_depth = 10, had_threads = 128;
     DevBuf  fb_jobs;                      // with Hadamard bundles: one flag per job, "an exhaustive kernel covers its integer stage"
     bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
@@ -531,11 +531,21 @@ void xcd_interleave(std::vector<T> &v)
 // planes up to 10 bits deep.  There a lane task is ONE candidate, a bundle may hold a single job (the
 // general kernel's scan is far slower), and a slab has at most 2^HAD_RIDX_BITS candidates.
 void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector<char> &in_bundle,
-               std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes)
+               std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes, int *had_threads_out = nullptr)
 {
     lds_bytes = 0;
     if (!had && bpp != 1)
         return;
+    // (candidate-per-lane kernel: windows of more than 48 x 48 candidates are shared by 4 wavefronts instead of 2, or
+    // too few wavefronts fit a CU beside each other's windows; one workgroup size per launch)
+    int had_threads = HAD_THREADS;
+    if (had)
+        for (int i = 0; i < n; i++)
+            if (had_kernel_eligible(jobs[i], bpp) && !in_bundle[i] &&
+                (jobs[i].mvmax_x - jobs[i].mvmin_x >= 48 || jobs[i].mvmax_y - jobs[i].mvmin_y >= 48))
+                had_threads = HAD_THREADS_BIG;
+    if (had_threads_out)
+        *had_threads_out = had_threads;
     auto fl = [](int v) { return v >= 0 ? v / 64 : -((-v + 63) / 64); };
     auto zidx = [](int cx, int cy) {
         return (cx & 1) | ((cy & 1) << 1) | ((cx & 2) << 1) | ((cy & 2) << 2) | ((cx & 4) << 2) | ((cy & 4) << 3); };
@@ -549,7 +559,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         const int gx = fl(j.pu_x), gy = fl(j.pu_y);
         if ((j.pu_x - gx * 64) % j.w || (j.pu_y - gy * 64) % j.h)
             continue;
-        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
+        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
     }
     for (auto &g : groups)
     {
@@ -575,7 +585,10 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                     B.cells |= 1ull << zidx(cx + xx, cy + yy);
             x0 = std::min(x0, (int)j.mvmin_x); y0 = std::min(y0, (int)j.mvmin_y);
             x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
-            old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1);
+            // (16-bit SAD: k_full_items reaches 19 / 36 / 52 / 43 % of the v_sad_u16 rate at 8 / 16 / 32 / 64 wide PUs,
+            // the candidate-per-lane kernel about 36 % on the cells it measures)
+            const double eff = !had ? 1.0 : j.w == 8 ? 0.19 / 0.36 : j.w == 16 ? 0.35 / 0.36 : j.w == 32 ? 0.52 / 0.36 : 0.43 / 0.36;
+            old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1) / eff;
         }
         if (taken.size() < (had ? 1u : 2u))
             continue;
@@ -583,7 +596,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if ((int64_t)nxw * nyw > (1 << HIER_RIDX_BITS))
             continue;
         const double hier_work = (double)__builtin_popcountll(B.cells) * 64.0 * nxw * nyw;
-        if (!had && hier_work * 1.25 > old_work)
+        const bool sad16 = had && jobs[g.second[0]].icost == X265AMD_SAD;
+        if (!had ? hier_work * 1.25 > old_work : sad16 && hier_work > old_work)
             continue;
         B.uniform = 1;
         for (int i : taken)
@@ -593,9 +607,11 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         B.ctu_x = gx * 64; B.ctu_y = gy * 64;
         B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
+        B.metric = j0.icost;
         // slabs of about one lane task per thread
         const int ppd = 4 / bpp;
-        const int XG = had ? nxw : (nxw + 3) >> 2;                              // lane tasks per task row
+        const int NC = had_nc(sad16);                                           // candidates per lane task (me_had.h)
+        const int XG = had ? (nxw + NC - 1) / NC : (nxw + 3) >> 2;              // lane tasks per task row
         const int RT = had ? 1 : HIER_R;                                        // candidate rows per task row
         const int nd = had ? (nxw + 67 + ppd - 1) / ppd + 1 : XG + 16;          // (the widest row read of had_load_row ends 11 pixels behind its first)
         int pitch = nd, best = 64;
@@ -612,13 +628,14 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         }
         // slabs of one lane task per thread (more per thread only when that would exceed the FullBest slots)
         const int nquads = (nyw + RT - 1) / RT, ntasks = nquads * XG;
-        const int threads = had ? HAD_THREADS : HIER_THREADS;
+        const int threads = had ? had_threads : HIER_THREADS;
         int per = threads;
         while ((ntasks + per - 1) / per > FB_STRIDE_PLAN)
             per += threads;
-        if (had && per > (1 << HAD_RIDX_BITS))
+        if (had && per * NC > (1 << HAD_RIDX_BITS))
             continue;
-        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * HIER_WAVES * HIER_SMALL + 8 * HIER_WAVES * 5 + 64;
+        const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
+        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64;
         bool fits = true;
         std::vector<HierItem> mine;
         for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
@@ -694,8 +711,9 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     std::vector<HierBundle> dbundles;
     std::vector<HierItem> ditems;
     L->n_had_bundles = L->n_had_items = L->had_lds_bytes = 0;
-    if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the Hadamard kernel off)
-        plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes);
+    const std::vector<char> in_hier = in_bundle;
+    if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the candidate-per-lane kernel off)
+        plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes, &L->had_threads);
     if (!ditems.empty())
     {
         xcd_interleave(ditems);
@@ -704,14 +722,22 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         if (int rc = ensure(c, L->had_bundles, dbundles.size() * sizeof(HierBundle))) return rc;
         if (int rc = ensure(c, L->had_items, ditems.size() * sizeof(HierItem))) return rc;
         if (int rc = ensure(c, L->had_fenc, dbundles.size() * (size_t)HAD_FENC_DW * 4)) return rc;
-        if (int rc = ensure(c, L->fb_jobs, (size_t)n)) return rc;
+        if (int rc = ensure(c, L->fb_jobs, 2 * (size_t)n)) return rc;
+        L->had_max_depth = 12;
+        for (const HierBundle &B : dbundles)
+            if (B.metric != X265AMD_SAD)
+                L->had_max_depth = 10;
         HIPCHK(c, hipMemcpyAsync(L->had_bundles.p, dbundles.data(), dbundles.size() * sizeof(HierBundle), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L->had_items.p, ditems.data(), ditems.size() * sizeof(HierItem), hipMemcpyHostToDevice, c->stream));
         // (every SAD job the exhaustive kernels accept is planned below; of the SA8D jobs, those bundled here)
-        std::vector<unsigned char> flags(n);
+        // second half: the flags of a run whose planes are too deep for this kernel (its bundles fall to the general kernel's scan)
+        std::vector<unsigned char> flags(2 * (size_t)n);
         for (int i = 0; i < n; i++)
+        {
             flags[i] = full_kernel_eligible(jobs[i], bpp) || in_bundle[i];
-        HIPCHK(c, hipMemcpyAsync(L->fb_jobs.p, flags.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+            flags[n + i] = full_kernel_eligible(jobs[i], bpp) && !(in_bundle[i] && !in_hier[i]);
+        }
+        HIPCHK(c, hipMemcpyAsync(L->fb_jobs.p, flags.data(), flags.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // flags dies here
     }
     if (!hitems.empty())
@@ -815,13 +841,14 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
     delete L;
 }
 
-// The Hadamard kernel works on packed 16-bit differences: usable while every plane of the run is at most 10 bits deep
+// The candidate-per-lane kernel works on packed 16-bit differences and 21-bit costs: usable while every plane of
+// the run is at most 10 bits deep (SA8D bundles) or 12 (SAD only)
 bool had_usable(x265amd_ctx *c, const x265amd_joblist *L, const BatchParams &P)
 {
-    if (!L->n_had_items || c->h_planes[P.enc_plane].depth > 10)
+    if (!L->n_had_items || c->h_planes[P.enc_plane].depth > L->had_max_depth)
         return false;
     for (int r = 0; r < P.n_refs; r++)
-        if (c->h_planes[P.ref_planes[r]].depth > 10)
+        if (c->h_planes[P.ref_planes[r]].depth > L->had_max_depth)
             return false;
     return true;
 }
@@ -851,7 +878,7 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
 #define XA_LAUNCH_HAD(PIX)                                                                                         \
         hipLaunchKernelGGL(k_pack_fenc16<PIX>, dim3(L->n_had_bundles), dim3(256), 0, st, P,                        \
                            (const HierBundle*)L->had_bundles.p, L->n_had_bundles, (uint32_t*)L->had_fenc.p);       \
-        hipLaunchKernelGGL(k_full_had<PIX>, dim3(L->n_had_items), dim3(HAD_THREADS), L->had_lds_bytes, st, P,      \
+        hipLaunchKernelGGL(k_full_had<PIX>, dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P,      \
                            (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,                  \
                            (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,        \
                            (FullBest*)L->fb.p, FB_STRIDE_PLAN)
@@ -894,7 +921,7 @@ int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams 
 {
     BatchParams P = P0;
     P.hist = L->keep_hist ? (unsigned*)L->hist.p : nullptr;
-    P.fb_jobs = had_usable(c, L, P) ? (const unsigned char*)L->fb_jobs.p : nullptr;
+    P.fb_jobs = !L->n_had_items ? nullptr : (const unsigned char*)L->fb_jobs.p + (had_usable(c, L, P) ? 0 : L->n);
     L->ran = true;
     return launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n,
                           (const int*)L->idx.p, L->cls_count,
