@@ -248,8 +248,12 @@ struct JobLds
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
     static constexpr bool LR = LR_;
+    // A window of the reference plane around the search centre is kept in LDS only by the class of the largest PUs:
+    // measured on MI355X, staging it costs the smaller classes more instructions than reading candidates from the
+    // plane (L2) does (8x8 .. 32x32 PUs: 3 - 14 % faster without, 64x64: 6 - 16 % slower without).
+    static constexpr bool USE_WIN = MAXG >= 1024;
     // window bytes for 8-bit pixels: the square PU of the class with the full margin (long thin PUs get less margin)
-    static constexpr int WIN_BYTES = (MAXG >= 1024 ? 8704 : MAXG >= 256 ? 4352 : 2560) * (int)sizeof(PIX);
+    static constexpr int WIN_BYTES = USE_WIN ? 8704 * (int)sizeof(PIX) : 0;
 
     uint32_t fenc[MAXG * DW];                   // encoder pixels of group g (cached PU, encoder/motion.cpp:104-119)
     uint16_t gxy[MAXG];                         // (y << 8) | x of group g inside the PU
@@ -1046,7 +1050,7 @@ struct Dev
     {
         const int n = uni(n_), cflags = uni(cflags_);
         View v(base);
-        const bool lw = (cflags & CF_WINDOW) != 0;
+        const bool lw = L::USE_WIN && (cflags & CF_WINDOW) != 0;
         const int pitch = lw ? v.s->wpitch : v.s->stride;
         Src src(v, lw);
         const int mv = label_cost(v, n, cflags);
@@ -1320,7 +1324,7 @@ struct Dev
     {
         const int n = uni(n_), cflags = uni(cflags_), kind = uni(kind_);
         View v(base);
-        const bool lw = (cflags & CF_WINDOW) != 0;
+        const bool lw = L::USE_WIN && (cflags & CF_WINDOW) != 0;
         const int pitch = lw ? v.s->wpitch : v.s->stride;
         Src src(v, lw);
         int res = label_cost(v, n, cflags);     // lane k collects candidate k
@@ -1514,7 +1518,7 @@ struct Wave
     // Returns CF_WINDOW or 0.
     __device__ __forceinline__ int place(int minx, int miny, int maxx, int maxy, bool may_restage)
     {
-        if (jflags & JF_NO_WINDOW)
+        if (!L::USE_WIN || (jflags & JF_NO_WINDOW))
             return 0;
         if (wvalid && minx - 3 >= wx0 && maxx + w + 5 <= wx0 + ww && miny - 3 >= wy0 && maxy + h + 4 <= wy0 + wh)
             return CF_WINDOW;
