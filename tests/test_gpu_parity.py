@@ -289,6 +289,23 @@ def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits,
              J.frame_jobs(W, H, sizes=(32, 16), subme=0, merange=64, qp=30, **kw)[:12]]
     x, y = J.square_pu_grid(W, H, 32)
     parts.append(J.make_jobs(W, H, x[::3], y[::3], 32, 16, subme=0, merange=10, qp=27, **kw))
+    # every rectangular / asymmetric partition of the CUs of 16, 32 and 64 pixels (those made of 8x8 cells share the pass;
+    # the 4- and 12-pixel ones of the 16-pixel CUs are priced with SATD by the reference and take the general kernel)
+    rx, ry, rw, rh = [], [], [], []
+    for n2 in (16, 32, 64):
+        q = n2 // 4
+        for cy in range(0, H - n2 + 1, n2):
+            for cx in range(0, W - n2 + 1, n2):
+                for (ox, oy, w, h) in ((0, 0, n2, n2 // 2), (0, n2 // 2, n2, n2 // 2), (0, 0, n2 // 2, n2), (n2 // 2, 0, n2 // 2, n2),
+                                       (0, 0, n2, q), (0, q, n2, n2 - q), (0, 0, n2, n2 - q), (0, n2 - q, n2, q),
+                                       (0, 0, q, n2), (q, 0, n2 - q, n2), (0, 0, n2 - q, n2), (n2 - q, 0, q, n2)):
+                    rx.append(cx + ox); ry.append(cy + oy); rw.append(w); rh.append(h)
+    rx, ry, rw, rh = (np.array(a) for a in (rx, ry, rw, rh))
+    for (w, h) in sorted(set(zip(rw.tolist(), rh.tolist()))):
+        sel = (rw == w) & (rh == h)
+        parts.append(J.make_jobs(W, H, rx[sel], ry[sel], w, h, subme=0, merange=7, qp=27, **kw))
+        if bits == 16:
+            parts.append(J.make_jobs(W, H, rx[sel][::2], ry[sel][::2], w, h, method=J.FULL, subme=0, merange=11, qp=27, qmvp=(-3, 2)))
     # the SAD metric through the same pass (16-bit planes): all levels, single small / large levels, bidirectional refinement
     parts += [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=33, qmvp=(5, -9)),
               J.frame_jobs(W, H, sizes=(8,), method=J.FULL, subme=1, merange=16, qp=22),

@@ -27,6 +27,7 @@ constexpr int HAD_THREADS = 128;          // workgroup size of a launch whose wi
 constexpr int HAD_THREADS_BIG = 512;      // large (the wavefronts that share a staged window decide how many fit a CU)
 constexpr int HAD_WAVES = HAD_THREADS_BIG / 64;   // slot rows in LDS
 constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11 (a slab has at most 2^11 candidates), costs of 16x16 and below < 2^21
+static_assert(HAD_THREADS >= HIER_MAX_RECT, "one thread per rectangular PU writes its partial winner");
 constexpr int HAD_FENC_DW = 2048;         // packed encoder block: 64 cells x 8 rows x 4 dwords (8 pixels as 16-bit pairs)
 
 // Re-pack the 64x64 encoder block of every bundle as 16-bit pixels: cell z (Z-order) -> 32 consecutive
@@ -189,7 +190,16 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
+    // bundles with rectangular PUs (launched with HAD_THREADS threads): 64-bit slots [waves][HIER_MAX_RECT], then per thread
+    // the values of the 16 cells of the running 32x32 block and of the 16 finished 16x16 blocks ([16][threads][NC] each)
+    const int n_rect = B.rect_end[4];
+    unsigned long long *s_rk = s_big + HAD_WAVES * 5;
+    uint32_t *s_cell = (uint32_t*)(s_rk + (HAD_THREADS / 64) * HIER_MAX_RECT);
+    uint32_t *s_quad = s_cell + 16 * HAD_THREADS * NC;
     {
+        if (n_rect)
+            for (int i = tid; i < (HAD_THREADS / 64) * HIER_MAX_RECT; i += nthreads)
+                s_rk[i] = ~0ull;
         const uint8_t *r0 = (const uint8_t*)ref.origin;
         const int64_t lo = ref.lo, hi = ref.hi - PPD;
         const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + y_lo;
@@ -264,6 +274,37 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
             return k;
         };
+        // rectangular PUs [k0, k1) of the bundle from the table `tab` ([16][threads][NC] values; cells: rounded per 8x8 here)
+        auto rects = [&](int k0, int k1, const uint32_t *tab, bool cell_values) {
+#pragma nounroll
+            for (int k = k0; k < k1; k++)
+            {
+                const int jid = B.rect[k].job;
+                uint32_t mask = B.rect[k].mask;
+                uint32_t v[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    v[c] = 0;
+#pragma nounroll
+                while (mask)
+                {
+                    const int b = __builtin_ctz(mask);
+                    mask &= mask - 1;
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                    {
+                        const uint32_t t = tab[(b * HAD_THREADS + tid) * NC + c];
+                        v[c] += (!SAD && cell_values) ? (t + 1) >> 1 : t;
+                    }
+                }
+                const unsigned long long m = wave_min_u64(key64(jid, v));
+                if (lane == 0)
+                {
+                    unsigned long long *sl = s_rk + wv * HIER_MAX_RECT + k;
+                    *sl = m < *sl ? m : *sl;
+                }
+            }
+        };
         uint64_t rem = cells;
         int z = rem ? __builtin_ctzll(rem) : 64;
 #pragma nounroll
@@ -305,7 +346,11 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
 #pragma unroll
             for (int c = 0; c < NC; c++)
+            {
                 q16[c] += h[c];
+                if (n_rect)
+                    s_cell[((z & 15) * HAD_THREADS + tid) * NC + c] = h[c];
+            }
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
                 const int q = z >> 2;
@@ -315,6 +360,8 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 {
                     v16[c] = SAD ? q16[c] : (q16[c] + 1) >> 1;           // (S8a + S8b + S8c + S8d + 2) >> 2
                     q16[c] = 0;
+                    if (n_rect)
+                        s_quad[(q * HAD_THREADS + tid) * NC + c] = v16[c];
                 }
                 const int j16 = B.job[64 + q];
                 if (j16 >= 0)
@@ -332,6 +379,8 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
                 {
                     const int q32 = z >> 4;
+                    if (n_rect)
+                        rects(q32 ? B.rect_end[q32 - 1] : 0, B.rect_end[q32], s_cell, true);
                     const int j32 = B.job[80 + q32];
                     if (j32 >= 0)
                     {
@@ -352,6 +401,8 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
             z = nz;
         }
+        if (n_rect)
+            rects(B.rect_end[3], n_rect, s_quad, false);
         const int j64 = B.job[84];
         if (j64 >= 0)
         {
@@ -405,6 +456,21 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
             fb[(size_t)jid * fb_stride + it.slot] = f;
         }
+    }
+    if (tid < n_rect)           // (bundles with rectangular PUs run with HAD_THREADS >= HIER_MAX_RECT threads)
+    {
+        unsigned long long m = ~0ull;
+        for (int w = 0; w < nwaves; w++)
+        {
+            const unsigned long long v = s_rk[w * HIER_MAX_RECT + tid];
+            m = v < m ? v : m;
+        }
+        FullBest f;
+        const int ridx = m != ~0ull ? (int)(m & 0xffffffffu) : -1;
+        f.cost = m != ~0ull ? (int)(m >> 32) : 0x7fffffff;
+        f.mvx = ridx < 0 ? 0 : (int16_t)(B.mvx0 + ridx % nxw);
+        f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
+        fb[(size_t)B.rect[tid].job * fb_stride + it.slot] = f;
     }
 }
 

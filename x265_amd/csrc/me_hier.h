@@ -37,6 +37,7 @@ constexpr int HIER_PUS = 85;              // 64 + 16 + 4 + 1 squares of the quad
 constexpr int HIER_SMALL = 80;            // PUs 0..79 (8x8, 16x16) use 32-bit keys
 constexpr int HIER_RIDX_BITS = 15;        // raster index bits: window candidates <= 2^15
 constexpr int HIER_FENC_DW = 1024;        // packed encoder block: 64 cells x 16 dwords
+constexpr int HIER_MAX_RECT = 128;        // rectangular PUs of one bundle (me_had.h; every 8-aligned HEVC shape of a CTU: 124)
 // 32-bit keys: (SAD + mvcost) << 15 | raster index.  The kernel is used only while no MV-cost table entry
 // exceeds HIER_MVCOST_MAX / 2 (the reference's tables peak at 3381, encoder/bitcost.cpp:48-56 with the
 // largest lambda), so a valid key stays below (65280 + 8191) << 15 | 32767 < HIER_KEY_NONE, and every
@@ -55,7 +56,11 @@ struct HierBundle
     int32_t  metric;            // X265AMD_SAD / X265AMD_SA8D: the jobs' integer-stage metric (me_had.h; me_hier.h is SAD only)
     uint64_t cells;             // bit z: 8x8 cell z (Z-order) is covered by some job
     int32_t  job[HIER_PUS];     // job of square k (0..63: 8x8 in Z-order, 64..79: 16x16, 80..83: 32x32, 84: 64x64), -1: none
-    int32_t  pad2;
+    // Rectangular PUs (me_had.h only), sorted by group: groups 0..3 = PUs made of 8x8 cells of 32x32 block g
+    // (mask bit = cell's Z-order index inside the block), group 4 = PUs made of whole 16x16 blocks (mask bit =
+    // the block's Z-order index inside the 64x64 cell).  rect_end[g] = end of group g in rect[].
+    int32_t  rect_end[5];
+    struct Rect { int32_t job; uint32_t mask; } rect[HIER_MAX_RECT];
 };
 
 // A work item: lane tasks [t_lo, t_hi) of a bundle, in raster order of (row quad, x group)

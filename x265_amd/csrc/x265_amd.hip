@@ -538,26 +538,49 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         return;
     // (candidate-per-lane kernel: windows of more than 48 x 48 candidates are shared by 4 wavefronts instead of 2, or
     // too few wavefronts fit a CU beside each other's windows; one workgroup size per launch)
+    // (a launch with rectangular PUs keeps per-thread tables of cell values in LDS, sized for the small workgroup)
     int had_threads = HAD_THREADS;
     if (had)
+    {
+        bool any_rect = false;
         for (int i = 0; i < n; i++)
-            if (had_kernel_eligible(jobs[i], bpp) && !in_bundle[i] &&
-                (jobs[i].mvmax_x - jobs[i].mvmin_x >= 48 || jobs[i].mvmax_y - jobs[i].mvmin_y >= 48))
-                had_threads = HAD_THREADS_BIG;
+            if (had_kernel_eligible(jobs[i], bpp) && !in_bundle[i])
+            {
+                const x265amd_me_job &j = jobs[i];
+                if (j.mvmax_x - j.mvmin_x >= 48 || j.mvmax_y - j.mvmin_y >= 48)
+                    had_threads = HAD_THREADS_BIG;
+                any_rect = any_rect || j.w != j.h || (j.w & (j.w - 1)) || ((j.pu_x | j.pu_y) & (j.w - 1));
+            }
+        if (any_rect)
+            had_threads = HAD_THREADS;
+    }
     if (had_threads_out)
         *had_threads_out = had_threads;
     auto fl = [](int v) { return v >= 0 ? v / 64 : -((-v + 63) / 64); };
     auto zidx = [](int cx, int cy) {
         return (cx & 1) | ((cy & 1) << 1) | ((cx & 2) << 1) | ((cy & 2) << 2) | ((cx & 4) << 2) | ((cy & 4) << 3); };
+    // a square of the quadtree of cell (gx, gy)?
+    auto is_square = [](const x265amd_me_job &j, int gx, int gy) {
+        return j.w == j.h && (j.w == 8 || j.w == 16 || j.w == 32 || j.w == 64) &&
+               (j.pu_x - gx * 64) % j.w == 0 && (j.pu_y - gy * 64) % j.h == 0; };
+    // Another PU made of whole 8x8 cells of cell (gx, gy) (candidate-per-lane kernel)?  2: of whole aligned 16x16 blocks
+    // (the unit sa8d_inter rounds in when both sides are multiples of 16, common/pixel.cpp:313-362), 1: of 8x8 cells inside
+    // one 32x32 block (sa8d_inter rounds per 8x8), 0: neither.
+    auto rect_kind = [](const x265amd_me_job &j, int gx, int gy) {
+        const int ox = j.pu_x - gx * 64, oy = j.pu_y - gy * 64;
+        if (((j.w | j.h | ox | oy) & 7) || ox + j.w > 64 || oy + j.h > 64)
+            return 0;
+        if (((j.w | j.h) & 15) == 0)
+            return ((ox | oy) & 15) == 0 ? 2 : 0;
+        return (ox >> 5) == ((ox + j.w - 1) >> 5) && (oy >> 5) == ((oy + j.h - 1) >> 5) ? 1 : 0; };
     std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < n; i++)
     {
         const x265amd_me_job &j = jobs[i];
-        if (!(had ? had_kernel_eligible(j, bpp) : full_kernel_eligible(j, bpp)) || in_bundle[i] ||
-            j.w != j.h || (j.w != 8 && j.w != 16 && j.w != 32 && j.w != 64))
+        if (!(had ? had_kernel_eligible(j, bpp) : full_kernel_eligible(j, bpp)) || in_bundle[i])
             continue;
         const int gx = fl(j.pu_x), gy = fl(j.pu_y);
-        if ((j.pu_x - gx * 64) % j.w || (j.pu_y - gy * 64) % j.h)
+        if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy)))
             continue;
         groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
     }
@@ -571,14 +594,32 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
         double old_work = 0;
         std::vector<int> taken;
+        std::vector<HierBundle::Rect> rects[5];
         for (int i : g.second)
         {
             const x265amd_me_job &j = jobs[i];
             const int cx = (j.pu_x - gx * 64) >> 3, cy = (j.pu_y - gy * 64) >> 3, z = zidx(cx, cy);
-            const int k = j.w == 8 ? z : j.w == 16 ? 64 + (z >> 2) : j.w == 32 ? 80 + (z >> 4) : 84;
-            if (B.job[k] >= 0)
-                continue;               // the same PU twice: the second one is scanned on its own
-            B.job[k] = i;
+            if (is_square(j, gx, gy))
+            {
+                const int k = j.w == 8 ? z : j.w == 16 ? 64 + (z >> 2) : j.w == 32 ? 80 + (z >> 4) : 84;
+                if (B.job[k] >= 0)
+                    continue;           // the same PU twice: the second one is scanned on its own
+                B.job[k] = i;
+            }
+            else
+            {
+                size_t total = 0;
+                for (auto &r : rects)
+                    total += r.size();
+                if (total >= (size_t)HIER_MAX_RECT)
+                    continue;
+                HierBundle::Rect r = { i, 0u };
+                const bool quads = rect_kind(j, gx, gy) == 2;
+                for (int yy = 0; yy < (j.h >> 3); yy++)
+                    for (int xx = 0; xx < (j.w >> 3); xx++)
+                        r.mask |= 1u << (quads ? zidx(cx + xx, cy + yy) >> 2 : zidx(cx + xx, cy + yy) & 15);
+                rects[quads ? 4 : z >> 4].push_back(r);
+            }
             taken.push_back(i);
             for (int yy = 0; yy < (j.h >> 3); yy++)
                 for (int xx = 0; xx < (j.w >> 3); xx++)
@@ -587,7 +628,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
             // (16-bit SAD: k_full_items reaches 19 / 36 / 52 / 43 % of the v_sad_u16 rate at 8 / 16 / 32 / 64 wide PUs,
             // the candidate-per-lane kernel about 36 % on the cells it measures)
-            const double eff = !had ? 1.0 : j.w == 8 ? 0.19 / 0.36 : j.w == 16 ? 0.35 / 0.36 : j.w == 32 ? 0.52 / 0.36 : 0.43 / 0.36;
+            const double eff = !had ? 1.0 : j.w <= 8 ? 0.19 / 0.36 : j.w <= 16 ? 0.35 / 0.36 : j.w <= 32 ? 0.52 / 0.36 : 0.43 / 0.36;
             old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1) / eff;
         }
         if (taken.size() < (had ? 1u : 2u))
@@ -608,6 +649,13 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
         B.metric = j0.icost;
+        int n_rect = 0;
+        for (int gk = 0; gk < 5; gk++)
+        {
+            for (const HierBundle::Rect &r : rects[gk])
+                B.rect[n_rect++] = r;
+            B.rect_end[gk] = n_rect;
+        }
         // slabs of about one lane task per thread
         const int ppd = 4 / bpp;
         const int NC = had_nc(sad16);                                           // candidates per lane task (me_had.h)
@@ -635,7 +683,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if (had && per * NC > (1 << HAD_RIDX_BITS))
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
-        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64;
+        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
+                          (n_rect ? 8 * (HAD_THREADS / 64) * HIER_MAX_RECT + 2 * 16 * HAD_THREADS * NC * 4 : 0);
         bool fits = true;
         std::vector<HierItem> mine;
         for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
