@@ -431,6 +431,40 @@ def main():
                          "value": look[LOOK_PAIRS][1] / (look[LOOK_PAIRS][0] * 1e-3), "unit": "evals/s",
                          "single_pair_kernel_ms": look[1][0], "lowres_init_us_per_picture": lowres_us}
 
+    # ---- 4K 10-bit, Hadamard integer stage (BASELINE configs[4]'s metric): exhaustive +-16 SA8D search of every
+    # square PU 64/32/16/8 in one list; the candidate-per-lane kernel prices the 8x8 cells once for all four levels
+    W4, H4 = 3840, 2160
+    seq4 = synth.make_sequence(W4, H4, 2, seed=5, bit_depth=10)
+    ids4 = [eng.upload_plane(f, bit_depth=10) for f in seq4]
+    had_jobs = J.frame_jobs(W4, H4, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=16, qp=27, icost=J.SA8D)
+    jl_had = eng.make_joblist(had_jobs, bytes_per_px=2)
+    for _ in range(2):
+        jl_had.run(ids4[1], [ids4[0]], fetch=False)
+    eng.sync()
+    eng.eval_count(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        jl_had.run(ids4[1], [ids4[0]], fetch=False)
+    eng.sync()
+    had_dt = (time.perf_counter() - t0) / args.steps
+    had_evals = eng.eval_count() / args.steps
+    k_had_ms, k_had_tail_ms = eng.kernel_times()
+    had_res = jl_had.results()
+    jl_had.close()
+    had_ops = float(sum(7.0 * s * s * J.full_search_evals(had_jobs[had_jobs["w"] == s]) for s in (64, 32, 16, 8)))
+    line["sa8d_full_4k10"] = {"workload": "4K 10-bit synthetic, exhaustive +-16 integer search with the SA8D metric of every square PU "
+                                          "64/32/16/8, subme 0 (BASELINE configs[4]'s metric and pixel type)",
+                              "jobs_per_frame": int(len(had_jobs)), "evals_per_frame": had_evals, "value": had_evals / had_dt,
+                              "unit": "evals/s", "ms_per_frame": had_dt * 1e3,
+                              "roofline": {"bound": "valu", "kernel": "k_full_had<uint16_t>", "achieved": had_ops / (k_had_ms * 1e-3) / 1e12,
+                                           "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s",
+                                           "frac": had_ops / (k_had_ms * 1e-3) / (cus * 64 * clk_hz), "kernel_ms": k_had_ms,
+                                           "search_kernel_ms": k_had_tail_ms, "algorithmic_ops_per_launch": had_ops,
+                                           "ops_def": "SA8D evaluation = 7*w*h integer operations; algorithmic = every PU's candidates x its "
+                                                      "own pixels (the kernel prices each 8x8 cell once for the four levels, so frac can exceed 1)"}}
+    for i in ids4:
+        eng.release_plane(i)
+
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_ffi as F
@@ -468,7 +502,10 @@ def main():
         ok = bool(np.array_equal(chk, hex_res[::5]))
         fsel = np.arange(0, len(full_jobs), 400)
         chk, _ = o.search(enc_np, [ref_np], full_jobs[fsel], threads=8)
-        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, full_res[fsel]))
+        ok = ok and bool(np.array_equal(chk, full_res[fsel]))
+        hsel = np.arange(0, len(had_jobs), 997)
+        chk, _ = o.search(seq4[1], [seq4[0]], had_jobs[hsel], threads=8, bit_depth=10)
+        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, had_res[hsel]))
 
     print(json.dumps(line), flush=True)
 

@@ -4,7 +4,7 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 print("value %.4g %s  ms_per_step %.4f  k_search ms %.4f  roofline frac %.4g  parity %s" %
       (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d.get("parity_sample_ok")))
-print("dia %.4g ms/frame %.4f | pcie ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"], d["pcie_inclusive"]["ms_per_frame"]))
+print("dia %.4g ms/frame %.4f | pcie ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"], d["pcie_inclusive"]["full_search"]["ms_per_frame"]))
 f = d["full_search"]
 print("full: %.4g evals/s  ms/frame %.3f  k_full ms %.3f frac %.3f  tail ms %.3f" %
       (f["value"], f["ms_per_frame"], f["roofline"]["kernel_ms"], f["roofline"]["frac"], f["roofline"]["search_kernel_ms"]))
