@@ -2,17 +2,25 @@
 """Print the headline numbers of a bench.py JSON line."""
 import json, sys
 d = json.load(open(sys.argv[1]))
-print("value %.4g %s  ms_per_step %.4f  k_search ms %.4f  roofline frac %.4g  parity %s" %
-      (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d.get("parity_sample_ok")))
-print("dia %.4g ms/frame %.4f | pcie ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"], d["pcie_inclusive"]["full_search"]["ms_per_frame"]))
-f = d["full_search"]
-print("full: %.4g evals/s  ms/frame %.3f  k_full ms %.3f frac %.3f  tail ms %.3f" %
-      (f["value"], f["ms_per_frame"], f["roofline"]["kernel_ms"], f["roofline"]["frac"], f["roofline"]["search_kernel_ms"]))
+r = d["roofline"]
+print("value %.4g %s  ms_per_step %.4f  exhaustive kernels %.4f ms (frac %.3f, executed %.3f)  tail %.4f ms  parity %s" %
+      (d["value"], d["unit"], d["ms_per_step"], r["kernel_ms"], r["frac"], r.get("executed_frac", 0), r.get("search_kernel_ms", 0),
+       d.get("parity_sample_ok")))
+if "hex_search" in d:
+    h = d["hex_search"]
+    print("hex: %.4g evals/s  ms/frame %.4f  k_search %.4f ms  valu frac %.4f" % (h["value"], h["ms_per_frame"], h["roofline"]["kernel_ms"], h["roofline"]["frac"]))
+    print("dia: %.4g evals/s  ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"]))
+    p = d["pcie_inclusive"]
+    print("pcie-inclusive ms/frame: full %.4f  hex %.4f" % (p["full_search"]["ms_per_frame"], p["hex_search"]["ms_per_frame"]))
+if "sa8d_full_4k10" in d:
+    s = d["sa8d_full_4k10"]
+    print("sa8d 4K 10-bit: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms" %
+          (s["value"], s["ms_per_frame"], s["roofline"]["kernel_ms"], s["roofline"]["search_kernel_ms"]))
 if "lookahead" in d:
     l = d["lookahead"]
     print("lookahead: %d pairs %.3f ms  (%.0f pairs/s, %.4g evals/s)  single pair %.3f ms  lowres init %.1f us  cpu %s  parity %s" %
           (l["pairs_per_call"], l["kernel_ms_per_call"], l["frame_pairs_per_s"], l["value"], l["single_pair_kernel_ms"],
            l["lowres_init_us_per_picture"], l.get("cpu_baseline", {}).get("ms_per_frame_pair"), l.get("parity_ok")))
-for k in ("cpu_baseline", "cpu_baseline_full_search", "cpu_baseline_all_cores"):
-    if k in d:
-        print(k, "%.4g" % d[k]["value"], d[k]["unit"], d[k]["cores"], d[k]["kind"])
+if "cpu_baseline" in d:
+    c = d["cpu_baseline"]
+    print("cpu_baseline %.4g %s  cores %d  %s  (%s)" % (c["value"], c["unit"], c["cores"], c["kind"], c.get("path", "")))
