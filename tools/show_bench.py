@@ -21,6 +21,6 @@ if "lookahead" in d:
     print("lookahead: %d pairs %.3f ms  (%.0f pairs/s, %.4g evals/s)  single pair %.3f ms  lowres init %.1f us  cpu %s  parity %s" %
           (l["pairs_per_call"], l["kernel_ms_per_call"], l["frame_pairs_per_s"], l["value"], l["single_pair_kernel_ms"],
            l["lowres_init_us_per_picture"], l.get("cpu_baseline", {}).get("ms_per_frame_pair"), l.get("parity_ok")))
-if "cpu_baseline" in d:
+if d.get("cpu_baseline"):
     c = d["cpu_baseline"]
     print("cpu_baseline %.4g %s  cores %d  %s  (%s)" % (c["value"], c["unit"], c["cores"], c["kind"], c.get("path", "")))

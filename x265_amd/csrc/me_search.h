@@ -20,6 +20,43 @@ struct FullBest
     int16_t mvx, mvy;   // full-pel
 };
 
+// Winner over the n (<= 16) slab partials of one job: lowest cost, then lowest raster index, as a serial raster scan
+// with strict `<` keeps it.  Lane s reads slot s; out of line, so that the kernel body keeps only uniform control flow.
+// Returns the cost in lane 0's x and the MV word (mvy << 16 | mvx & 0xffff) in y; cost INT32_MAX: no candidate.
+struct SlabBest { int cost, mv; };
+static __device__ __noinline__ SlabBest combine_slabs(const FullBest *fb, int n_, int nxr_, int minx_, int miny_)
+{
+    const int n = uni(n_), nxr = uni(nxr_), minx = uni(minx_), miny = uni(miny_);
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long key = ~0ull;
+    int mv = 0;
+    if (lane < n)
+    {
+        const FullBest f = fb[lane];
+        mv = ((int)f.mvy << 16) | ((int)f.mvx & 0xffff);
+        if (f.cost != 0x7fffffff)
+            key = ((unsigned long long)(uint32_t)f.cost << 32) | (uint32_t)((f.mvy - miny) * nxr + (f.mvx - minx));
+    }
+    unsigned long long m = key;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1)
+    {
+        const unsigned long long o = __shfl_xor(m, d);
+        m = o < m ? o : m;
+    }
+    m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    SlabBest r;
+    r.cost = 0x7fffffff;
+    r.mv = 0;
+    if (m != ~0ull)
+    {
+        const unsigned long long hit = __ballot(key == m);
+        r.cost = (int)(m >> 32);
+        r.mv = __shfl(mv, __builtin_ctzll(hit));
+    }
+    return r;
+}
+
 // (32-bit entries: uniform lookups then compile to scalar loads, which have no byte form on this target)
 __constant__ int c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
 __constant__ int c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
@@ -430,16 +467,8 @@ struct Search
             // minimum in raster order, which is what strict-`<` updates would have kept
             // combine the slabs: lowest cost, then lowest raster index
             const int nxr = j.mvmax_x - j.mvmin_x + 1;
-            int fcost = 0x7fffffff, fidx = 0x7fffffff, fx = 0, fy = 0;
-            for (int s = 0; s < fb_stride; s++)
-            {
-                int c = uni(fb[s].cost), x = uni(fb[s].mvx), y = uni(fb[s].mvy);   // (vector loads: pin to scalar registers)
-                int idx = (y - j.mvmin_y) * nxr + (x - j.mvmin_x);
-                if (c < fcost || (c == fcost && c != 0x7fffffff && idx < fidx))
-                {
-                    fcost = c; fidx = idx; fx = x; fy = y;
-                }
-            }
+            const SlabBest sb = combine_slabs(fb, fb_stride > 16 ? 16 : fb_stride, nxr, j.mvmin_x, j.mvmin_y);
+            const int fcost = uni(sb.cost), fmv = uni(sb.mv), fx = XA_S16(fmv & 0xffff), fy = XA_S16(fmv >> 16);
             if (fcost < bcost)
             {
                 bcost = fcost;
