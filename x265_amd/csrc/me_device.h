@@ -237,6 +237,9 @@ struct JobState
     int32_t  pts[8];                // candidates of the next eval call: offset of the block origin (window bytes / plane pixels)
     int32_t  lbl[8];                // their labels for MV pricing: (y << 16) | (x & 0xffff), q-pel
     int32_t  frc[8];                // their fractional phases xf | yf << 2 (eval_any)
+#ifdef XA_PROFILE
+    long long cpt[4];               // developer aid: clock at entry of eval_any, after the MV costs, after the pixel work, at exit
+#endif
 };
 
 // LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64).
@@ -1213,6 +1216,10 @@ struct Dev
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 d[i] = act ? f.v[i] - r.v[i] : 0;
+#ifdef XA_PROFILE
+            if (c0 == 0)
+                v.s->cpt[2] = (long long)__builtin_readcyclecounter() + (__builtin_amdgcn_readfirstlane(d[0]) & 0);
+#endif
             int a0 = 0;
             accum(am, d, v.lane, a0, a0);
             int tot = sum16(a0);                        // the row's (= the candidate's) total in every lane of the row
@@ -1327,10 +1334,16 @@ struct Dev
         const bool lw = L::USE_WIN && (cflags & CF_WINDOW) != 0;
         const int pitch = lw ? v.s->wpitch : v.s->stride;
         Src src(v, lw);
+#ifdef XA_PROFILE
+        v.s->cpt[0] = (long long)__builtin_readcyclecounter();
+#endif
         int res = label_cost(v, n, cflags);     // lane k collects candidate k
         int par = (cflags & CF_PAR) ? 1 : 0;
         if (L::LR && (uni(v.s->frc[0]) & LR_FLAG))
         {
+#ifdef XA_PROFILE
+            v.s->cpt[1] = (long long)__builtin_readcyclecounter() + (__builtin_amdgcn_readfirstlane(res) & 0);
+#endif
             if (NW == 1 && v.G <= 16) lr_batch_rows(v, src, kind, n, res);
             else if (n == 1) lr_batch<1>(v, src, kind, par, res);
             else if (n <= 4) lr_batch<4>(v, src, kind, par, res);
@@ -1339,6 +1352,9 @@ struct Dev
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 r.c[k] = __builtin_amdgcn_readlane(res, k);
+#ifdef XA_PROFILE
+            v.s->cpt[3] = (long long)__builtin_readcyclecounter() + (r.c[0] & 0);
+#endif
             return r;
         }
         if constexpr (NW == 1 && DW == 1)
@@ -1436,6 +1452,7 @@ struct Wave
     unsigned evals;
 #ifdef XA_PROFILE                   // developer aid: shader-clock stamps at phase boundaries of the search
     long long tstamp[8];
+    long long cprof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // eval_any calls: count, set-up, call -> entry, MV costs, pixel work, reduce, return, unpack
     __device__ __forceinline__ void stamp(int k) { tstamp[k] = (long long)__builtin_readcyclecounter(); }
 #else
     __device__ __forceinline__ void stamp(int) {}
@@ -1561,6 +1578,9 @@ struct Wave
             minx = x < minx ? x : minx; maxx = x > maxx ? x : maxx;
             miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
         }
+#ifdef XA_PROFILE
+        const long long t_a = (long long)__builtin_readcyclecounter();
+#endif
         const bool multi = kind == X265AMD_SAD && !frac;
         // a lone full-pel SAD (predictor checks, clipped pattern points) does not move the window;
         // phases of a half-resolution set select other planes than the one the window caches
@@ -1595,7 +1615,23 @@ struct Wave
                     s->frc[k] = 0;
             }
             D::post(base, D::OP_ANY, n, cf, kind);
+#ifdef XA_PROFILE
+            const long long t_b = (long long)__builtin_readcyclecounter();
+#endif
             r = D::eval_any(base, n, cf, kind);
+#ifdef XA_PROFILE
+            if (frac && lowres)
+            {
+                const long long t_c = (long long)__builtin_readcyclecounter() + (uni(r.c[0]) & 0);
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    out[k] = uni(r.c[k]);
+                const long long t_d = (long long)__builtin_readcyclecounter() + (out[0] & 0);
+                const long long e0 = s->cpt[0], e1 = s->cpt[1], e2 = s->cpt[2], e3 = s->cpt[3];
+                cprof[0] += 1; cprof[1] += t_b - t_a; cprof[2] += e0 - t_b; cprof[3] += e1 - e0; cprof[4] += e2 - e1;
+                cprof[5] += e3 - e2; cprof[6] += t_c - e3; cprof[7] += t_d - t_c;
+            }
+#endif
         }
 #pragma unroll
         for (int k = 0; k < N; k++)

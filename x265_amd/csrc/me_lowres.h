@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(64) k_lookahead(const PlaneDesc *planes, const
 #ifdef XA_PROFILE
     if (threadIdx.x == 0 && (blockIdx.x & 7) == 0)
         for (int k = 0; k < 8; k++)
+        {
             atomicAdd(evals + EVAL_SLOTS * 16 + 8 + k, (unsigned long long)prof[k]);
+            atomicAdd(evals + (EVAL_SLOTS + 1) * 16 + k, (unsigned long long)W.cprof[k]);
+        }
 #endif
 }
 

@@ -45,7 +45,7 @@ struct DevBuf
 
 } // namespace
 
-constexpr int EVAL_WORDS = (EVAL_SLOTS + 1) * 16;   // device words behind d_evals
+constexpr int EVAL_WORDS = (EVAL_SLOTS + 2) * 16;   // device words behind d_evals
 
 struct x265amd_ctx
 {
@@ -2047,6 +2047,11 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
         if (q[15])
             fprintf(stderr, "lookahead rows (sampled), clocks: cache PU %llu  wait for the row below %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu  | whole CU loop %llu\n",
                     q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]);
+        const unsigned long long *cq = &t[(size_t)(EVAL_SLOTS + 1) * 16];
+        if (cq[0])
+            fprintf(stderr, "half-resolution sub-pel calls (sampled rows): %llu calls; clocks per call: set-up %llu  call -> entry %llu  MV costs %llu  "
+                            "plane reads %llu  reduce %llu  return %llu  unpack %llu\n", cq[0], cq[1] / cq[0], cq[2] / cq[0], cq[3] / cq[0],
+                    cq[4] / cq[0], cq[5] / cq[0], cq[6] / cq[0], cq[7] / cq[0]);
         unsigned long long fp[8], zero[8] = { 0 };
         HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_full_prof), sizeof(fp)));
         if (fp[4])
