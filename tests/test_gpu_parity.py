@@ -322,6 +322,39 @@ def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits,
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("depth", [12, 14])
+def test_shared_pass_limits_fall_back_to_the_other_kernels(eng, oracle, depth):
+    """What the candidate-per-lane exhaustive kernel does not take must come out right through the other kernels:
+    16-bit planes deeper than its packed 16-bit arithmetic allows (SA8D: 10 bits, SAD: 12 bits), more rectangular PUs in
+    one 64x64 cell than a bundle holds (the same partition listed many times), rectangles with a +-40 window (small
+    workgroups although the window is large), PUs straddling two cells, and 4- / 12-pixel sides."""
+    W, H = 136, 136
+    rng = np.random.default_rng(depth)
+    a = rng.integers(0, 1 << depth, (H, W)).astype(np.int32)
+    b = np.roll(a, (2, -3), (0, 1))
+    b[::7, ::5] = (1 << depth) - 1
+    fr = [synth.pad_plane(a, depth), synth.pad_plane(b, depth)]
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    parts = []
+    for icost in (J.SAD, J.SA8D):
+        kw = dict(method=J.FULL, subme=0, qp=30, icost=icost)
+        parts += [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), merange=6, **kw),
+                  J.make_jobs(W, H, [0] * 150, [0] * 150, 16, 8, merange=5, **kw),          # one partition 150 times
+                  J.make_jobs(W, H, [0, 16, 32, 64], [8, 0, 32, 64], 32, 8, merange=40, **kw),
+                  J.make_jobs(W, H, [48, 56, 40], [48, 8, 56], 32, 32, merange=6, **kw),     # straddle cell borders
+                  J.make_jobs(W, H, [0, 16, 64], [0, 32, 64], 16, 12, merange=6, **kw),
+                  J.make_jobs(W, H, [0, 16, 64], [0, 32, 64], 4, 16, merange=6, **kw)]
+    jobs = np.concatenate(parts)
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+    eng.eval_count(reset=True)
+    got = eng.search(ids[0], [ids[1]], jobs)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_device_resident_and_planned_paths_agree(eng, oracle):
     """The three ways in (host batch, raw device job array, planned job list) give identical,
     oracle-exact results; the job list mixes FULL jobs of every size class with pattern searches."""
