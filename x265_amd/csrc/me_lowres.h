@@ -133,8 +133,8 @@ struct LookLeaf
         }
         return w;
     }
-    // one lane publishes a CU's result
-    static __device__ __noinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost)
+    // one lane publishes a CU's result (inline: a call would wait for the store to complete before it returns)
+    static __device__ __forceinline__ void publish(x265amd_me_result *out, int mvx, int mvy, int cost)
     {
         if (threadIdx.x == 0)
         {
