@@ -304,8 +304,7 @@ def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits,
     for (w, h) in sorted(set(zip(rw.tolist(), rh.tolist()))):
         sel = (rw == w) & (rh == h)
         parts.append(J.make_jobs(W, H, rx[sel], ry[sel], w, h, subme=0, merange=7, qp=27, **kw))
-        if bits == 16:
-            parts.append(J.make_jobs(W, H, rx[sel][::2], ry[sel][::2], w, h, method=J.FULL, subme=0, merange=11, qp=27, qmvp=(-3, 2)))
+        parts.append(J.make_jobs(W, H, rx[sel][::2], ry[sel][::2], w, h, method=J.FULL, subme=0, merange=11, qp=27, qmvp=(-3, 2)))
     # the SAD metric through the same pass (16-bit planes): all levels, single small / large levels, bidirectional refinement
     parts += [J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=0, merange=24, qp=33, qmvp=(5, -9)),
               J.frame_jobs(W, H, sizes=(8,), method=J.FULL, subme=1, merange=16, qp=22),

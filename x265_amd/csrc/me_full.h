@@ -158,7 +158,7 @@ __device__ __forceinline__ unsigned long long scan_job(const uint32_t *win, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tiny PUs (at most 16 dwords: 8x8, 8x4, 4x8, 4x4, 16x4).  The whole encoder block sits in scalar
+// Tiny PUs (at most 16 dwords in 4 or 8 rows: 8x8, 8x4, 4x8, 4x4, 12x4, 16x4; a 4x16 PU takes the general scan).  The whole encoder block sits in scalar
 // registers, a lane task is 4 x-candidates x 4 candidate rows (every window dword pair feeds four
 // candidate rows), the row loop is fully unrolled, and no flush is needed (<= 64 pixels per
 // candidate).  The winner is tracked as ONE 32-bit key (cost << 15 | raster index): the cost of a
@@ -458,7 +458,7 @@ __device__ void full_item_body(const BatchParams &P, const x265amd_me_job *jobs,
                 const int wy = j.pu_y + j.mvmin_y + ty0 - (it.win_y0 + (it.win_rows ? 0 : ty0 - it.y_lo));
                 const uint16_t *cx = (const uint16_t*)(scr + h * W4 * PB);
                 unsigned long long b;
-                if (PB == 1 && W4 <= 4 && h * W4 <= 16 && it.win_rows && nx * ny <= (1 << TINY_KEY_SHIFT))
+                if (PB == 1 && W4 <= 4 && (h == 4 || h == 8) && h * W4 <= 16 && it.win_rows && nx * ny <= (1 << TINY_KEY_SHIFT))
                 {
                     // tiny PU: encoder block into scalar registers (dword i from lane i)
                     constexpr int TW4 = W4 <= 4 ? W4 : 1;

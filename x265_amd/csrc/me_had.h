@@ -1,7 +1,8 @@
 // Exhaustive (FULL_SEARCH) integer stage with the SA8D metric for all square PUs of a 64x64 picture cell
 // from one pass over the search window (8- and 16-bit pixels up to 10 bits deep), and the same pass with
-// the SAD metric for 16-bit planes up to 12 bits deep (v_sad_u16 on the same packed pairs; 8-bit SAD has
-// the quad-SAD kernel of me_hier.h).
+// the SAD metric: 16-bit planes up to 12 bits deep (v_sad_u16 on the same packed pairs, two candidates per
+// lane), and 8-bit planes (v_qsad_pk_u16_u8, four candidates per lane) for what the quad-SAD kernel of
+// me_hier.h does not take: rectangular partitions and cells with a single PU.
 //
 // sa8d_inter of a square PU is built from 8x8 Hadamard sums S8 (common/pixel.cpp:276-362, 756-826):
 //   8x8           (S8 + 2) >> 2
@@ -20,6 +21,8 @@
 #pragma once
 
 #include "me_hier.h"
+
+#include <type_traits>
 
 namespace xa {
 
@@ -41,6 +44,20 @@ __global__ void __launch_bounds__(256) k_pack_fenc16(BatchParams P, const HierBu
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const HierBundle &B = bundles[b];
     const PIX *org = (const PIX*)enc.origin;
+    if (sizeof(PIX) == 1 && B.metric == X265AMD_SAD)
+    {
+        // 8-bit SAD bundles compare bytes: cell z -> 16 consecutive dwords, row r, half k at [2 r + k] (as k_pack_fenc)
+        for (int i = threadIdx.x; i < HIER_FENC_DW; i += 256)
+        {
+            const int z = i >> 4, r = (i >> 1) & 7, k = i & 1;
+            int cx, cy;
+            hier_cell_xy(z, cx, cy);
+            int64_t o = (int64_t)(B.ctu_y + cy * 8 + r) * enc.stride + B.ctu_x + cx * 8 + 4 * k;
+            o = o < enc.lo ? enc.lo : (o > enc.hi - 4 ? enc.hi - 4 : o);
+            packed[(size_t)b * HAD_FENC_DW + i] = ld_u32((const uint8_t*)org + o);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < HAD_FENC_DW; i += 256)
     {
         const int z = i >> 5, r = (i >> 2) & 7, k = i & 3;
@@ -167,15 +184,34 @@ __device__ __forceinline__ void sad8x8_pair_u16(const uint32_t *wbase, int pitch
     h[1] = s1;
 }
 
-// candidates per lane task: 2 for the SAD variant, 1 for SA8D
-__device__ __host__ constexpr int had_nc(bool sad) { return sad ? 2 : 1; }
+// SAD variant (8-bit planes): a lane owns FOUR horizontally adjacent candidates (x a multiple of 4): v_qsad_pk_u16_u8
+// prices the four byte-shifted positions of a 4-pixel group at once; f = the cell's 16 encoder dwords (bytes).
+__device__ __forceinline__ void sad8x8_quad_u8(const uint32_t *wbase, int pitch, int e, const uint32_t *f, uint32_t *h)
+{
+    unsigned long long acc = 0;
+    const uint32_t *d = wbase + (e >> 2);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(lds_pair(d + r * pitch), f[2 * r], acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(lds_pair(d + r * pitch + 1), f[2 * r + 1], acc);
+    }
+    h[0] = (uint32_t)acc & 0xffffu;
+    h[1] = (uint32_t)acc >> 16;
+    h[2] = (uint32_t)(acc >> 32) & 0xffffu;
+    h[3] = (uint32_t)(acc >> 48);
+}
+
+// candidates per lane task: SAD: 2 (16-bit pixels) or 4 (8-bit); SA8D: 1
+__device__ __host__ constexpr int had_nc(bool sad, int bytes_per_px) { return !sad ? 1 : bytes_per_px == 2 ? 2 : 4; }
 
 template <typename PIX, bool MASK, bool SAD>
 __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
                                               const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
 {
-    constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB, NC = had_nc(SAD);
-    static_assert(!SAD || PB == 2, "the SAD variant is for 16-bit planes");
+    constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB, NC = had_nc(SAD, PB);
+    constexpr bool SAD8 = SAD && PB == 1;               // byte SADs: 16 encoder dwords per cell, cell / block values fit 16 bits
+    typedef typename std::conditional<SAD8, uint16_t, uint32_t>::type TabT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
@@ -194,8 +230,8 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     // the values of the 16 cells of the running 32x32 block and of the 16 finished 16x16 blocks ([16][threads][NC] each)
     const int n_rect = B.rect_end[4];
     unsigned long long *s_rk = s_big + HAD_WAVES * 5;
-    uint32_t *s_cell = (uint32_t*)(s_rk + (HAD_THREADS / 64) * HIER_MAX_RECT);
-    uint32_t *s_quad = s_cell + 16 * HAD_THREADS * NC;
+    TabT *s_cell = (TabT*)(s_rk + (HAD_THREADS / 64) * HIER_MAX_RECT);
+    TabT *s_quad = s_cell + 16 * HAD_THREADS * NC;
     {
         if (n_rect)
             for (int i = tid; i < (HAD_THREADS / 64) * HIER_MAX_RECT; i += nthreads)
@@ -275,7 +311,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             return k;
         };
         // rectangular PUs [k0, k1) of the bundle from the table `tab` ([16][threads][NC] values; cells: rounded per 8x8 here)
-        auto rects = [&](int k0, int k1, const uint32_t *tab, bool cell_values) {
+        auto rects = [&](int k0, int k1, const TabT *tab, bool cell_values) {
 #pragma nounroll
             for (int k = k0; k < k1; k++)
             {
@@ -314,13 +350,16 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             const int nz = rem ? __builtin_ctzll(rem) : 64;
             int cx, cy;
             hier_cell_xy(z, cx, cy);
-            const XA_CONST uint32_t *fe = pf + z * 32;
-            uint32_t f[32];
+            constexpr int FDW = SAD8 ? 16 : 32;
+            const XA_CONST uint32_t *fe = pf + z * FDW;
+            uint32_t f[FDW];
 #pragma unroll
-            for (int e = 0; e < 32; e++)
+            for (int e = 0; e < FDW; e++)
                 f[e] = fe[e];
             uint32_t h[NC];                                              // the cell's SAD, or S8 / 2
-            if constexpr (SAD)
+            if constexpr (SAD8)
+                sad8x8_quad_u8(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, h);
+            else if constexpr (SAD)
                 sad8x8_pair_u16(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, h);
             else
             {
@@ -349,7 +388,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             {
                 q16[c] += h[c];
                 if (n_rect)
-                    s_cell[((z & 15) * HAD_THREADS + tid) * NC + c] = h[c];
+                    s_cell[((z & 15) * HAD_THREADS + tid) * NC + c] = (TabT)h[c];
             }
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
@@ -361,7 +400,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                     v16[c] = SAD ? q16[c] : (q16[c] + 1) >> 1;           // (S8a + S8b + S8c + S8d + 2) >> 2
                     q16[c] = 0;
                     if (n_rect)
-                        s_quad[(q * HAD_THREADS + tid) * NC + c] = v16[c];
+                        s_quad[(q * HAD_THREADS + tid) * NC + c] = (TabT)v16[c];
                 }
                 const int j16 = B.job[64 + q];
                 if (j16 >= 0)
@@ -488,13 +527,10 @@ __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, con
     const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HAD_FENC_DW);
     if (B.metric == X265AMD_SAD)
     {
-        if constexpr (sizeof(PIX) == 2)
-        {
-            if (B.uniform)
-                had_item_body<PIX, false, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
-            else
-                had_item_body<PIX, true, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
-        }
+        if (B.uniform)
+            had_item_body<PIX, false, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        else
+            had_item_body<PIX, true, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
     }
     else if (B.uniform)
         had_item_body<PIX, false, false>(P, jobs, B, it, pf, fb, fb_stride, lds);

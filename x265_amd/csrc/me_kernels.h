@@ -30,8 +30,7 @@ __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
            nx > 0 && ny > 0 && nx <= FULL_MAX_CAND && ny <= FULL_MAX_CAND;
 }
 
-// Can the candidate-per-lane exhaustive kernel (me_had.h) take this job?  SA8D metric on any plane, or SAD
-// on 16-bit planes; bounded range.  (The caller also checks that the PU is a square of a 64x64 cell's
+// Can the candidate-per-lane exhaustive kernel (me_had.h) take this job?  SA8D or SAD metric; bounded range.  (The caller also checks that the PU is a square of a 64x64 cell's
 // quadtree and, at launch, the planes' bit depth: at most 10 for SA8D, 12 for SAD.)
 template <class J>
 __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
@@ -41,7 +40,7 @@ __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
         return false;
     if (j.icost == X265AMD_SA8D)
         return j.method == X265AMD_FULL;
-    return bpp == 2 && full_kernel_eligible(j, bpp);
+    return full_kernel_eligible(j, bpp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -626,9 +626,10 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                     B.cells |= 1ull << zidx(cx + xx, cy + yy);
             x0 = std::min(x0, (int)j.mvmin_x); y0 = std::min(y0, (int)j.mvmin_y);
             x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
-            // (16-bit SAD: k_full_items reaches 19 / 36 / 52 / 43 % of the v_sad_u16 rate at 8 / 16 / 32 / 64 wide PUs,
-            // the candidate-per-lane kernel about 36 % on the cells it measures)
-            const double eff = !had ? 1.0 : j.w <= 8 ? 0.19 / 0.36 : j.w <= 16 ? 0.35 / 0.36 : j.w <= 32 ? 0.52 / 0.36 : 0.43 / 0.36;
+            // (16-bit SAD: k_full_items reaches 19 / 36 / 52 / 43 % of the v_sad_u16 rate at 8 / 16 / 32 / 64 wide PUs, the
+            // candidate-per-lane kernel about 36 % on the cells it measures; 8-bit: 39 / 50 / 57 / 57 % against about 45 %)
+            const double eff = !had ? 1.0 : bpp == 2 ? (j.w <= 8 ? 0.19 / 0.36 : j.w <= 16 ? 0.35 / 0.36 : j.w <= 32 ? 0.52 / 0.36 : 0.43 / 0.36)
+                                                     : (j.w <= 8 ? 0.39 / 0.45 : j.w <= 16 ? 0.50 / 0.45 : 0.57 / 0.45);
             old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1) / eff;
         }
         if (taken.size() < (had ? 1u : 2u))
@@ -637,8 +638,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if ((int64_t)nxw * nyw > (1 << HIER_RIDX_BITS))
             continue;
         const double hier_work = (double)__builtin_popcountll(B.cells) * 64.0 * nxw * nyw;
-        const bool sad16 = had && jobs[g.second[0]].icost == X265AMD_SAD;
-        if (!had ? hier_work * 1.25 > old_work : sad16 && hier_work > old_work)
+        const bool had_sad = had && jobs[g.second[0]].icost == X265AMD_SAD;
+        if (!had ? hier_work * 1.25 > old_work : had_sad && hier_work > old_work)
             continue;
         B.uniform = 1;
         for (int i : taken)
@@ -658,7 +659,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         }
         // slabs of about one lane task per thread
         const int ppd = 4 / bpp;
-        const int NC = had_nc(sad16);                                           // candidates per lane task (me_had.h)
+        const int NC = had_nc(had_sad, bpp);                                    // candidates per lane task (me_had.h)
         const int XG = had ? (nxw + NC - 1) / NC : (nxw + 3) >> 2;              // lane tasks per task row
         const int RT = had ? 1 : HIER_R;                                        // candidate rows per task row
         const int nd = had ? (nxw + 67 + ppd - 1) / ppd + 1 : XG + 16;          // (the widest row read of had_load_row ends 11 pixels behind its first)
@@ -684,7 +685,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
         const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
-                          (n_rect ? 8 * (HAD_THREADS / 64) * HIER_MAX_RECT + 2 * 16 * HAD_THREADS * NC * 4 : 0);
+                          (n_rect ? 8 * (HAD_THREADS / 64) * HIER_MAX_RECT + 2 * 16 * HAD_THREADS * NC * (had_sad && bpp == 1 ? 2 : 4) : 0);
         bool fits = true;
         std::vector<HierItem> mine;
         for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
