@@ -310,13 +310,15 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
             return k;
         };
-        // rectangular PUs [k0, k1) of the bundle from the table `tab` ([16][threads][NC] values; cells: rounded per 8x8 here)
+        // rectangular PUs [k0, k1) of the bundle from the table `tab` ([16][threads][NC] values; cells: rounded per 8x8 here).
+        // Mask bit 31: the PU's cost may exceed the 21 bits of a 32-bit key (set by the planner from the PU's area).
         auto rects = [&](int k0, int k1, const TabT *tab, bool cell_values) {
 #pragma nounroll
             for (int k = k0; k < k1; k++)
             {
                 const int jid = B.rect[k].job;
-                uint32_t mask = B.rect[k].mask;
+                const uint32_t mword = B.rect[k].mask;
+                uint32_t mask = mword & 0xffffu;
                 uint32_t v[NC];
 #pragma unroll
                 for (int c = 0; c < NC; c++)
@@ -333,11 +335,22 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                         v[c] += (!SAD && cell_values) ? (t + 1) >> 1 : t;
                     }
                 }
-                const unsigned long long m = wave_min_u64(key64(jid, v));
-                if (lane == 0)
+                unsigned long long *sl = s_rk + wv * HIER_MAX_RECT + k;
+                if (mword >> 31)
                 {
-                    unsigned long long *sl = s_rk + wv * HIER_MAX_RECT + k;
-                    *sl = m < *sl ? m : *sl;
+                    const unsigned long long m = wave_min_u64(key64(jid, v));
+                    if (lane == 0)
+                        *sl = m < *sl ? m : *sl;
+                }
+                else
+                {
+                    const uint32_t m = hier_wave_min_last(key32(jid, v));
+                    if (lane == 63 && m != ~0u)
+                    {
+                        const unsigned long long m64 = ((unsigned long long)(m >> HAD_RIDX_BITS) << 32) |
+                                                       (uint32_t)(y_lo * nxw + x_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1)));
+                        *sl = m64 < *sl ? m64 : *sl;
+                    }
                 }
             }
         };

@@ -618,6 +618,10 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                 for (int yy = 0; yy < (j.h >> 3); yy++)
                     for (int xx = 0; xx < (j.w >> 3); xx++)
                         r.mask |= 1u << (quads ? zidx(cx + xx, cy + yy) >> 2 : zidx(cx + xx, cy + yy) & 15);
+                // (32-bit keys hold costs below 2^21: bound the PU's cost by its 8x8 cells' worst case plus the largest MV cost)
+                const double cell_max = j.icost == X265AMD_SA8D ? 131072.0 : 64.0 * (bpp == 1 ? 255.0 : 4095.0);
+                if ((j.w >> 3) * (j.h >> 3) * cell_max + HIER_MVCOST_MAX >= (double)(1 << 21))
+                    r.mask |= 0x80000000u;
                 rects[quads ? 4 : z >> 4].push_back(r);
             }
             taken.push_back(i);
@@ -627,9 +631,9 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             x0 = std::min(x0, (int)j.mvmin_x); y0 = std::min(y0, (int)j.mvmin_y);
             x1 = std::max(x1, (int)j.mvmax_x); y1 = std::max(y1, (int)j.mvmax_y);
             // (16-bit SAD: k_full_items reaches 19 / 36 / 52 / 43 % of the v_sad_u16 rate at 8 / 16 / 32 / 64 wide PUs, the
-            // candidate-per-lane kernel about 36 % on the cells it measures; 8-bit: 39 / 50 / 57 / 57 % against about 45 %)
+            // candidate-per-lane kernel about 36 % on the cells it measures; 8-bit: 39 / 50 / 57 / 57 % against about 30 %)
             const double eff = !had ? 1.0 : bpp == 2 ? (j.w <= 8 ? 0.19 / 0.36 : j.w <= 16 ? 0.35 / 0.36 : j.w <= 32 ? 0.52 / 0.36 : 0.43 / 0.36)
-                                                     : (j.w <= 8 ? 0.39 / 0.45 : j.w <= 16 ? 0.50 / 0.45 : 0.57 / 0.45);
+                                                     : (j.w <= 8 ? 0.39 / 0.30 : j.w <= 16 ? 0.50 / 0.30 : 0.57 / 0.30);
             old_work += (double)j.w * j.h * (j.mvmax_x - j.mvmin_x + 1) * (j.mvmax_y - j.mvmin_y + 1) / eff;
         }
         if (taken.size() < (had ? 1u : 2u))
