@@ -551,6 +551,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                     had_threads = HAD_THREADS_BIG;
                 any_rect = any_rect || j.w != j.h || (j.w & (j.w - 1)) || ((j.pu_x | j.pu_y) & (j.w - 1));
             }
+        if (const char *ev = getenv("X265AMD_HAD_THREADS"))     // tuning aid: 128, 256 or 512
+            had_threads = atoi(ev) >= 512 ? 512 : atoi(ev) >= 256 ? 256 : 128;
         if (any_rect)
             had_threads = HAD_THREADS;
     }
