@@ -26,8 +26,8 @@
 
 namespace xa {
 
-constexpr int HAD_THREADS = 128;          // workgroup size of a launch whose windows are small; HAD_THREADS_BIG when they are
-constexpr int HAD_THREADS_BIG = 512;      // large (the wavefronts that share a staged window decide how many fit a CU)
+constexpr int HAD_THREADS = 128;          // workgroup size of a launch with rectangular PUs (per-thread tables in LDS); without
+constexpr int HAD_THREADS_BIG = 512;      // them 256 threads, or HAD_THREADS_BIG when a window exceeds 48 x 48 candidates
 constexpr int HAD_WAVES = HAD_THREADS_BIG / 64;   // slot rows in LDS
 constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11 (a slab has at most 2^11 candidates), costs of 16x16 and below < 2^21
 static_assert(HAD_THREADS >= HIER_MAX_RECT, "one thread per rectangular PU writes its partial winner");

@@ -538,8 +538,10 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         return;
     // (candidate-per-lane kernel: windows of more than 48 x 48 candidates are shared by 4 wavefronts instead of 2, or
     // too few wavefronts fit a CU beside each other's windows; one workgroup size per launch)
-    // (a launch with rectangular PUs keeps per-thread tables of cell values in LDS, sized for the small workgroup)
-    int had_threads = HAD_THREADS;
+    // Workgroup size of the launch: the wavefronts that share a staged window decide how many fit a CU (measured: 4K
+    // +-16 SA8D 2.51 / 2.29 / 2.61 ms with 128 / 256 / 512 threads; 1080p 10-bit +-64 SAD 3.06 / 1.64 / 1.23 ms).  A launch
+    // with rectangular PUs keeps per-thread tables of cell values in LDS, sized for the small workgroup.
+    int had_threads = 256;
     if (had)
     {
         bool any_rect = false;
