@@ -299,6 +299,13 @@ int x265amd_lookahead_status(x265amd_ctx *ctx);
  * next x265amd_field_me on the context; x265amd_lookahead_status reports a row that gave up waiting). */
 int x265amd_field_me(x265amd_ctx *ctx, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method,
                      int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
+/* The same for n_fields (encoder plane, reference plane) pairs of one picture size and pixel type in one launch -
+ * e.g. the fields of a frame against each of its references (the loop over lists and references around
+ * TEncSearch.cpp:2425-2451).  A field's time is set by its chain of dependent PUs, not by throughput, so the
+ * fields of one call run side by side at about the time of one.  out / out_mvp hold field f at
+ * [f * (width / pu_w) * (height / pu_h) ...). */
+int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, int pu_w, int pu_h,
+                           int merange, int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
 const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last

@@ -152,7 +152,8 @@ int main(int argc, char **argv)
             me.setSearchMethod(1);
             me.setSubpelRefine(5);
             me.setQP(30);
-            field.runChained(pe, pr, pu, merange, 1, 5, 30);
+            // (two references in one device call; the walk below asks for the first one only)
+            field.runChained(pe, std::vector<x265amd::ReferencePlanes>{ pr, pe }, pu, merange, 1, 5, 30);
             me.attachField(&field);
             std::vector<x265amd::MV> dec(gw * gh);
             for (int gy = 0; gy < gh; gy++)

@@ -60,6 +60,35 @@ def test_1080p_field_matches_oracle(eng, oracle, pu, method, subme):
         eng.release_plane(i)
 
 
+def test_fields_of_several_references_in_one_call(eng, oracle):
+    """x265amd_field_me_batch: a frame against three references (and one pair the other way round) in one launch;
+    every field equals the single-field result of the oracle, and the call takes about as long as one field."""
+    W, H = 640, 368
+    fr = synth.make_sequence(W, H, 4, seed=23)
+    ids = [eng.upload_plane(f) for f in fr]
+    enc = [ids[3], ids[3], ids[3], ids[0]]
+    ref = [ids[2], ids[1], ids[0], ids[3]]
+    enc_np = [fr[3], fr[3], fr[3], fr[0]]
+    ref_np = [fr[2], fr[1], fr[0], fr[3]]
+    eng.eval_count(reset=True)
+    got, got_mvp = eng.field_me_batch(enc, ref, 16, 16, 32, J.HEX, 3, 30)
+    total = 0
+    for f in range(4):
+        exp, exp_mvp, evals = oracle.field_me(enc_np[f], ref_np[f], 16, 16, 32, J.HEX, 3, 30)
+        assert np.array_equal(got[f], exp), (f, np.argwhere(got[f] != exp)[:5])
+        assert np.array_equal(got_mvp[f], exp_mvp), f
+        total += evals
+    assert eng.eval_count() == total
+    with pytest.raises(Exception):
+        small = eng.upload_plane(synth.make_sequence(320, 192, 1, seed=1)[0])
+        try:
+            eng.field_me_batch([ids[3], small], [ids[2], small], 16, 16, 32, J.HEX, 3, 30)     # mixed picture sizes
+        finally:
+            eng.release_plane(small)
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_field_rejects_bad_arguments(eng):
     from x265_amd.api import X265AmdError
     fr = synth.make_sequence(128, 64, 2, seed=3)

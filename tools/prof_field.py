@@ -21,3 +21,8 @@ for pu, method, subme in ((16, J.HEX, 5), (8, J.HEX, 5), (32, J.HEX, 5), (64, J.
     n = (W // pu) * (H // pu)
     print("field %2dx%-2d method %d subme %d: %.3f ms per frame, %d PUs, chain %d, %.1f us per chained PU, %.3g evals/s"
           % (pu, pu, method, subme, ms, n, W // pu + 2 * (H // pu), ms * 1e3 / (W // pu + 2 * (H // pu)), ev / (ms * 1e-3)), flush=True)
+for nf in (2, 4, 8, 16):
+    for _ in range(2):
+        eng.field_me_batch([ids[1]] * nf, [ids[0]] * nf, 16, 16, 64, J.HEX, 5, 32, fetch=False)
+    ms = eng.kernel_times()[1]
+    print("field 16x16 HEX subme 5, %2d fields in one call: %.3f ms (%.3f ms per field)" % (nf, ms, ms / nf), flush=True)

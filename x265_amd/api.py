@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
     L.x265amd_ipfilter.argtypes = [vp, ci, vp, C.c_ssize_t, vp, C.c_ssize_t, ci, ci, ci, ci, ci]
     L.x265amd_lookahead_status.argtypes = [vp]
     L.x265amd_field_me.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.x265amd_field_me_batch.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_results_device.argtypes = [vp]
     L.x265amd_field_results_device.restype = vp
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
@@ -275,6 +276,21 @@ class Engine:
         mvp = np.zeros((gh, gw, 2), dtype=np.int16) if fetch else None
         self._chk(self.lib.x265amd_field_me(self.h, enc_plane, ref_plane, pu_w, pu_h, merange, method, subme, qp,
                                             out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
+        return (out, mvp) if fetch else None
+
+    def field_me_batch(self, enc_planes, ref_planes, pu_w: int, pu_h: int, merange: int, method: int, subme: int, qp: int,
+                       fetch: bool = True):
+        """the same for several (enc, ref) plane pairs of one picture size in one launch; returns
+        (results[n, gh, gw], mvp[n, gh, gw, 2]) or None with fetch=False"""
+        enc = np.ascontiguousarray(enc_planes, dtype=np.int32)
+        ref = np.ascontiguousarray(ref_planes, dtype=np.int32)
+        assert len(enc) == len(ref) and len(enc) > 0
+        w, h = self.plane_geometry(int(enc[0]))[:2]
+        gw, gh = w // pu_w, h // pu_h
+        out = np.zeros((len(enc), gh, gw), dtype=RESULT_DTYPE) if fetch else None
+        mvp = np.zeros((len(enc), gh, gw, 2), dtype=np.int16) if fetch else None
+        self._chk(self.lib.x265amd_field_me_batch(self.h, len(enc), enc.ctypes.data, ref.ctypes.data, pu_w, pu_h, merange, method,
+                                                  subme, qp, out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
         return (out, mvp) if fetch else None
 
     # -- costs --------------------------------------------------------------------------------

@@ -35,20 +35,23 @@
 namespace xa {
 
 template <class L>
-__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, int enc_plane, int ref_plane,
+__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
                                                  int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
                                                  int merange, int method, int subme, int qp, int flags,
                                                  x265amd_me_result *out, int *out_mvp, int *error, unsigned long long *evals)
 {
     __shared__ __align__(16) L lds;
-    const int gy = (int)blockIdx.x;                                     // workgroup 0: the top row
+    // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU rows of field f, top row first
+    const int field = (int)blockIdx.x / gh, gy = (int)blockIdx.x - field * gh;
+    out += (size_t)field * gw * gh;
+    out_mvp += (size_t)field * gw * gh;
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
     {
         Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
         return;
     }
-    const PlaneDesc &enc = planes[enc_plane];
-    const PlaneDesc &ref = planes[ref_plane];
+    const PlaneDesc &enc = planes[pairs[field].enc_plane];
+    const PlaneDesc &ref = planes[pairs[field].ref_plane];
     unsigned n_evals = 0;
     int failed = 0;
     int left = 0;                                                        // MV word of the PU searched last

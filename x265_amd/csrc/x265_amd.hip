@@ -1564,11 +1564,11 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
 extern "C++" {
 namespace {
 template <typename PIX>
-void launch_field(x265amd_ctx *c, int cls, int gh, const uint16_t *cost, int enc_plane, int ref_plane, int pu_w, int pu_h, int gw,
+void launch_field(x265amd_ctx *c, int cls, int n_fields, int gh, const uint16_t *cost, int pu_w, int pu_h, int gw,
                   int pic_w, int pic_h, int merange, int method, int subme, int qp, x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false>>), dim3(gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
-                                              enc_plane, ref_plane, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false>>), dim3(n_fields * gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
+                                              (const LookPair*)c->look_pairs.p, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
     else if (cls == 1) XA_FIELD(4, 256);
@@ -1578,32 +1578,44 @@ void launch_field(x265amd_ctx *c, int cls, int gh, const uint16_t *cost, int enc
 } // namespace
 } // extern "C++"
 
-int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method, int subme, int qp,
-                     x265amd_me_result *out, int16_t *out_mvp)
+int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, int pu_w, int pu_h, int merange,
+                           int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp)
 {
-    if (!c)
+    if (!c || n_fields < 1 || n_fields > 4096 || !enc_planes || !ref_planes)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    const int refs[1] = { ref_plane };
-    if (int rc = check_batch_planes(c, enc_plane, refs, 1)) return rc;
     if (!valid_dim(pu_w) || !valid_dim(pu_h) || method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 ||
         qp < 0 || qp > 51 || merange < 0 || merange > 32767 || (method == X265AMD_UMH && pu_w == 4 && pu_h == 4))
         return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
-    const PlaneDesc &e = c->h_planes[enc_plane], &r = c->h_planes[ref_plane];
-    if (e.lr_step || r.lr_step || e.width != r.width || e.height != r.height)
-        return fail(c, X265AMD_ERR_INVALID, "field search needs two full-resolution planes of one picture size");
-    // clipMv lets a block reach 64 + 8 - 1 pixels beyond the picture; plus pattern overshoot and the filter apron
-    if (r.margin_x < 71 + 3 + 4 || r.margin_y < 71 + 3 + 4)
-        return fail(c, X265AMD_ERR_RANGE, "reference margins below 78 pixels");
+    std::vector<LookPair> hp(n_fields);
+    for (int f = 0; f < n_fields; f++)
+    {
+        const int refs[1] = { ref_planes[f] };
+        if (int rc = check_batch_planes(c, enc_planes[f], refs, 1)) return rc;
+        const PlaneDesc &e = c->h_planes[enc_planes[f]], &r = c->h_planes[ref_planes[f]], &e0 = c->h_planes[enc_planes[0]];
+        if (e.lr_step || r.lr_step || e.width != r.width || e.height != r.height)
+            return fail(c, X265AMD_ERR_INVALID, "field search needs two full-resolution planes of one picture size");
+        if (e.width != e0.width || e.height != e0.height || e.bpp != e0.bpp)
+            return fail(c, X265AMD_ERR_INVALID, "the fields of one call must share picture size and pixel type");
+        // clipMv lets a block reach 64 + 8 - 1 pixels beyond the picture; plus pattern overshoot and the filter apron
+        if (r.margin_x < 71 + 3 + 4 || r.margin_y < 71 + 3 + 4)
+            return fail(c, X265AMD_ERR_RANGE, "reference margins below 78 pixels");
+        hp[f].enc_plane = enc_planes[f];
+        hp[f].ref_plane = ref_planes[f];
+    }
+    const PlaneDesc &e = c->h_planes[enc_planes[0]];
     const int gw = e.width / pu_w, gh = e.height / pu_h;
     if (gw < 1 || gh < 1)
         return fail(c, X265AMD_ERR_INVALID, "picture smaller than one PU");
-    const size_t n = (size_t)gw * gh;
+    const size_t n = (size_t)gw * gh * n_fields;
     if (int rc = sync_planes(c)) return rc;
     if (int rc = ensure(c, c->field_results, n * sizeof(x265amd_me_result))) return rc;
     if (int rc = ensure(c, c->field_mvp, n * sizeof(int))) return rc;
     if (int rc = ensure(c, c->look_progress, sizeof(int))) return rc;
+    if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // hp dies here
     HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->field_results.p, LOOK_UNSET, n * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
@@ -1612,10 +1624,10 @@ int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
     const int cls = job_class(pu_w, pu_h);
     if (e.bpp == 1)
-        launch_field<uint8_t>(c, cls, gh, cost, enc_plane, ref_plane, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
+        launch_field<uint8_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
                               (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
     else
-        launch_field<uint16_t>(c, cls, gh, cost, enc_plane, ref_plane, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
+        launch_field<uint16_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
                                (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
     HIPCHK(c, hipGetLastError());
     if (c->timing)
@@ -1634,6 +1646,12 @@ int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int
     if (h_err)
         return fail(c, X265AMD_ERR_HIP, "field search: a PU row waited too long for the row above it");
     return 0;
+}
+
+int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method, int subme, int qp,
+                     x265amd_me_result *out, int16_t *out_mvp)
+{
+    return x265amd_field_me_batch(c, 1, &enc_plane, &ref_plane, pu_w, pu_h, merange, method, subme, qp, out, out_mvp);
 }
 
 const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *c)

@@ -182,32 +182,48 @@ public:
     // call site whose neighbours carry the field's MVs - every PU coded inter with its ME result - hits.
     void runChained(const ReferencePlanes &enc, const ReferencePlanes &ref, int pu, int merange, int method, int subme, int qp)
     {
-        const int gw = enc.width / pu, gh = enc.height / pu;
-        std::vector<x265amd_me_result> res((size_t)gw * gh);
-        std::vector<int16_t> mvp((size_t)gw * gh * 2);
-        m_ctx.check(x265amd_field_me(m_ctx.get(), enc.plane_id, ref.plane_id, pu, pu, merange, method, subme, qp, res.data(), mvp.data()));
+        runChained(enc, std::vector<ReferencePlanes>(1, ref), pu, merange, method, subme, qp);
+    }
+    // The same against several references (the loop over lists and references around TEncSearch.cpp:2425-2451) in
+    // ONE device call: a field's time is its chain of dependent PUs, so the fields run side by side.
+    void runChained(const ReferencePlanes &enc, const std::vector<ReferencePlanes> &refs, int pu, int merange, int method, int subme, int qp)
+    {
+        const int gw = enc.width / pu, gh = enc.height / pu, nf = (int)refs.size();
+        const size_t per = (size_t)gw * gh;
+        std::vector<x265amd_me_result> all(per * nf);
+        std::vector<int16_t> allmvp(per * nf * 2);
+        std::vector<int> encs(nf, enc.plane_id), refids(nf);
+        for (int f = 0; f < nf; f++)
+            refids[f] = refs[f].plane_id;
+        m_ctx.check(x265amd_field_me_batch(m_ctx.get(), nf, encs.data(), refids.data(), pu, pu, merange, method, subme, qp,
+                                           all.data(), allmvp.data()));
         if (m_valid && m_enc != enc.plane_id)
             clear();
-        for (int gy = 0; gy < gh; gy++)
-            for (int gx = 0; gx < gw; gx++)
-            {
-                const int xy = gx + gy * gw;
-                x265amd_me_job j = x265amd_me_job();
-                j.pu_x = gx * pu; j.pu_y = gy * pu; j.w = j.h = (int16_t)pu;
-                MV p(mvp[2 * xy], mvp[2 * xy + 1]), lo, hi;
-                setSearchRange(p, merange, enc.width, enc.height, j.pu_x, j.pu_y, lo, hi);
-                j.mvmin_x = lo.x; j.mvmin_y = lo.y; j.mvmax_x = hi.x; j.mvmax_y = hi.y;
-                j.qmvp_x = p.x; j.qmvp_y = p.y;
-                j.merange = (int16_t)merange; j.method = (uint8_t)method; j.subme = (uint8_t)subme; j.qp = (uint8_t)qp;
-                j.numc = 3; j.icost = X265AMD_SAD;
-                if (gx > 0)                { j.mvc[0][0] = res[xy - 1].mvx;      j.mvc[0][1] = res[xy - 1].mvy; }
-                if (gy > 0)                { j.mvc[1][0] = res[xy - gw].mvx;     j.mvc[1][1] = res[xy - gw].mvy; }
-                if (gy > 0 && gx + 1 < gw) { j.mvc[2][0] = res[xy - gw + 1].mvx; j.mvc[2][1] = res[xy - gw + 1].mvy; }
-                const int at = add(ref, j);
-                if ((size_t)at >= m_results.size())
-                    m_results.resize(at + 1);
-                m_results[at] = res[xy];
-            }
+        for (int f = 0; f < nf; f++)
+        {
+            const x265amd_me_result *res = all.data() + per * f;
+            const int16_t *mvp = allmvp.data() + per * f * 2;
+            for (int gy = 0; gy < gh; gy++)
+                for (int gx = 0; gx < gw; gx++)
+                {
+                    const int xy = gx + gy * gw;
+                    x265amd_me_job j = x265amd_me_job();
+                    j.pu_x = gx * pu; j.pu_y = gy * pu; j.w = j.h = (int16_t)pu;
+                    MV p(mvp[2 * xy], mvp[2 * xy + 1]), lo, hi;
+                    setSearchRange(p, merange, enc.width, enc.height, j.pu_x, j.pu_y, lo, hi);
+                    j.mvmin_x = lo.x; j.mvmin_y = lo.y; j.mvmax_x = hi.x; j.mvmax_y = hi.y;
+                    j.qmvp_x = p.x; j.qmvp_y = p.y;
+                    j.merange = (int16_t)merange; j.method = (uint8_t)method; j.subme = (uint8_t)subme; j.qp = (uint8_t)qp;
+                    j.numc = 3; j.icost = X265AMD_SAD;
+                    if (gx > 0)                { j.mvc[0][0] = res[xy - 1].mvx;      j.mvc[0][1] = res[xy - 1].mvy; }
+                    if (gy > 0)                { j.mvc[1][0] = res[xy - gw].mvx;     j.mvc[1][1] = res[xy - gw].mvy; }
+                    if (gy > 0 && gx + 1 < gw) { j.mvc[2][0] = res[xy - gw + 1].mvx; j.mvc[2][1] = res[xy - gw + 1].mvy; }
+                    const int at = add(refs[f], j);
+                    if ((size_t)at >= m_results.size())
+                        m_results.resize(at + 1);
+                    m_results[at] = res[xy];
+                }
+        }
         m_enc = enc.plane_id;
         m_valid = true;
     }
