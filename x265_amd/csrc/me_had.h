@@ -26,8 +26,8 @@
 
 namespace xa {
 
-constexpr int HAD_THREADS = 128;          // workgroup size of a launch with rectangular PUs (per-thread tables in LDS); without
-constexpr int HAD_THREADS_BIG = 512;      // them 256 threads, or HAD_THREADS_BIG when a window exceeds 48 x 48 candidates
+constexpr int HAD_THREADS = 128;          // smallest workgroup of a launch (tuning aid); the default is 256 threads, or
+constexpr int HAD_THREADS_BIG = 512;      // HAD_THREADS_BIG when a window exceeds 48 x 48 candidates
 constexpr int HAD_WAVES = HAD_THREADS_BIG / 64;   // slot rows in LDS
 constexpr int HAD_RIDX_BITS = 11;         // 32-bit keys: slab-local candidate index < 2^11 (a slab has at most 2^11 candidates), costs of 16x16 and below < 2^21
 static_assert(HAD_THREADS >= HIER_MAX_RECT, "one thread per rectangular PU writes its partial winner");
@@ -205,13 +205,53 @@ __device__ __forceinline__ void sad8x8_quad_u8(const uint32_t *wbase, int pitch,
 // candidates per lane task: SAD: 2 (16-bit pixels) or 4 (8-bit); SA8D: 1
 __device__ __host__ constexpr int had_nc(bool sad, int bytes_per_px) { return !sad ? 1 : bytes_per_px == 2 ? 2 : 4; }
 
-template <typename PIX, bool MASK, bool SAD>
+// The rectangular partitions of HEVC inside a 64x64 cell (HierBundle::rect, `kind` below) follow from a few running
+// sums a lane keeps in registers:
+//   16x8 / 8x16 in a 16x16 block           pairs of its four cells;
+//   32x8, 32x24, 8x32, 24x32 (asymmetric)  row / column strips of cells of the 32x32 block (rounded per 8x8 for SA8D,
+//                                          as sa8d_inter does for sizes that are not multiples of 16);
+//   32x16 / 16x32                          pairs of the block's four 16x16 values;
+//   64x16, 64x48, 16x64, 48x64, 64x32, 32x64   row / column strips of the 16x16 values of the 64x64 cell.
+// kind: 0 = first strip, 1 = strips 1..3, 2 = strips 0..2, 3 = last strip (rows), 4..7 the same for columns,
+// 8 = upper half, 9 = lower half, 10 = left half, 11 = right half (of the four quarters in Z-order); 12 = strips 0..1,
+// 13 = strips 2..3 (rows), 14 / 15 the same for columns (the halves of the 64x64 cell).
+template <int NC>
+__device__ __forceinline__ void had_rect_value(int kind, const uint32_t (*S)[NC], const uint32_t (*T)[NC],
+                                               const uint32_t *Q0, const uint32_t *Q1, const uint32_t *Q2, const uint32_t *Q3, uint32_t *v)
+{
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+    {
+        uint32_t r;
+        switch (kind)
+        {
+        case 0:  r = S[0][c]; break;
+        case 1:  r = S[1][c] + S[2][c] + S[3][c]; break;
+        case 2:  r = S[0][c] + S[1][c] + S[2][c]; break;
+        case 3:  r = S[3][c]; break;
+        case 4:  r = T[0][c]; break;
+        case 5:  r = T[1][c] + T[2][c] + T[3][c]; break;
+        case 6:  r = T[0][c] + T[1][c] + T[2][c]; break;
+        case 7:  r = T[3][c]; break;
+        case 8:  r = Q0[c] + Q1[c]; break;
+        case 9:  r = Q2[c] + Q3[c]; break;
+        case 10: r = Q0[c] + Q2[c]; break;
+        case 11: r = Q1[c] + Q3[c]; break;
+        case 12: r = S[0][c] + S[1][c]; break;
+        case 13: r = S[2][c] + S[3][c]; break;
+        case 14: r = T[0][c] + T[1][c]; break;
+        default: r = T[2][c] + T[3][c]; break;
+        }
+        v[c] = r;
+    }
+}
+
+template <typename PIX, bool MASK, bool SAD, bool RECTS>
 __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
                                               const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
 {
     constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB, NC = had_nc(SAD, PB);
-    constexpr bool SAD8 = SAD && PB == 1;               // byte SADs: 16 encoder dwords per cell, cell / block values fit 16 bits
-    typedef typename std::conditional<SAD8, uint16_t, uint32_t>::type TabT;
+    constexpr bool SAD8 = SAD && PB == 1;               // byte SADs: 16 encoder dwords per cell
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
@@ -226,15 +266,12 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
-    // bundles with rectangular PUs (launched with HAD_THREADS threads): 64-bit slots [waves][HIER_MAX_RECT], then per thread
-    // the values of the 16 cells of the running 32x32 block and of the 16 finished 16x16 blocks ([16][threads][NC] each)
-    const int n_rect = B.rect_end[4];
+    // bundles with rectangular PUs: 64-bit slots [waves][HIER_MAX_RECT]
+    const int n_rect = RECTS ? B.rect_end[20] : 0;
     unsigned long long *s_rk = s_big + HAD_WAVES * 5;
-    TabT *s_cell = (TabT*)(s_rk + (HAD_THREADS / 64) * HIER_MAX_RECT);
-    TabT *s_quad = s_cell + 16 * HAD_THREADS * NC;
     {
-        if (n_rect)
-            for (int i = tid; i < (HAD_THREADS / 64) * HIER_MAX_RECT; i += nthreads)
+        if (RECTS)
+            for (int i = tid; i < nwaves * HIER_MAX_RECT; i += nthreads)
                 s_rk[i] = ~0ull;
         const uint8_t *r0 = (const uint8_t*)ref.origin;
         const int64_t lo = ref.lo, hi = ref.hi - PPD;
@@ -310,33 +347,35 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
             return k;
         };
-        // rectangular PUs [k0, k1) of the bundle from the table `tab` ([16][threads][NC] values; cells: rounded per 8x8 here).
-        // Mask bit 31: the PU's cost may exceed the 21 bits of a 32-bit key (set by the planner from the PU's area).
-        auto rects = [&](int k0, int k1, const TabT *tab, bool cell_values) {
+        // running sums for the rectangular PUs (had_rect_value): the last three cells / 16x16 values, the strips of cells of
+        // the running 32x32 block, the strips of 16x16 values of the 64x64 cell
+        uint32_t cprev[3][NC], qprev[3][NC], S[4][NC], T[4][NC], RQ[4][NC], CQ[4][NC];
+        if (RECTS)
+        {
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+            {
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    cprev[i][c] = qprev[i][c] = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    S[i][c] = T[i][c] = RQ[i][c] = CQ[i][c] = 0;
+            }
+        }
+        // rectangular PUs [k0, k1) of the bundle.  kind bit 31: the PU's cost may exceed the 21 bits of a 32-bit key (set
+        // by the planner from the PU's area).
+        auto rects = [&](int k0, int k1, const uint32_t (*St)[NC], const uint32_t (*Tt)[NC],
+                         const uint32_t *Q0, const uint32_t *Q1, const uint32_t *Q2, const uint32_t *Q3) {
 #pragma nounroll
             for (int k = k0; k < k1; k++)
             {
                 const int jid = B.rect[k].job;
-                const uint32_t mword = B.rect[k].mask;
-                uint32_t mask = mword & 0xffffu;
+                const uint32_t kword = B.rect[k].kind;
                 uint32_t v[NC];
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    v[c] = 0;
-#pragma nounroll
-                while (mask)
-                {
-                    const int b = __builtin_ctz(mask);
-                    mask &= mask - 1;
-#pragma unroll
-                    for (int c = 0; c < NC; c++)
-                    {
-                        const uint32_t t = tab[(b * HAD_THREADS + tid) * NC + c];
-                        v[c] += (!SAD && cell_values) ? (t + 1) >> 1 : t;
-                    }
-                }
+                had_rect_value<NC>((int)(kword & 0xffu), St, Tt, Q0, Q1, Q2, Q3, v);
                 unsigned long long *sl = s_rk + wv * HIER_MAX_RECT + k;
-                if (mword >> 31)
+                if (kword >> 31)
                 {
                     const unsigned long long m = wave_min_u64(key64(jid, v));
                     if (lane == 0)
@@ -382,14 +421,14 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                     had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
                 h[0] = had8x8_half(rows, f);
             }
+            uint32_t v8[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                v8[c] = SAD ? h[c] : (h[c] + 1) >> 1;                    // (S8 + 2) >> 2
             const int j8 = B.job[z];
             if (j8 >= 0)
             {
-                uint32_t v[NC];
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    v[c] = SAD ? h[c] : (h[c] + 1) >> 1;                 // (S8 + 2) >> 2
-                const uint32_t m = hier_wave_min_last(key32(j8, v));
+                const uint32_t m = hier_wave_min_last(key32(j8, v8));
                 if (lane == 63)
                 {
                     uint32_t *sl = s_slot + wv * HIER_SMALL + z;
@@ -398,10 +437,31 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             }
 #pragma unroll
             for (int c = 0; c < NC; c++)
-            {
                 q16[c] += h[c];
-                if (n_rect)
-                    s_cell[((z & 15) * HAD_THREADS + tid) * NC + c] = (TabT)h[c];
+            if (RECTS)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    if ((cy & 3) == i)
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            S[i][c] += v8[c];
+                    if ((cx & 3) == i)
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            T[i][c] += v8[c];
+                }
+                // (a 16x16 block with such PUs has all four cells covered, so they arrive one after the other)
+                if ((z & 3) == 3 && B.rect_end[z >> 2] != ((z >> 2) ? B.rect_end[(z >> 2) - 1] : 0))
+                    rects((z >> 2) ? B.rect_end[(z >> 2) - 1] : 0, B.rect_end[z >> 2], S, T, cprev[2], cprev[1], cprev[0], v8);
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                {
+                    cprev[2][c] = cprev[1][c];
+                    cprev[1][c] = cprev[0][c];
+                    cprev[0][c] = v8[c];
+                }
             }
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
@@ -412,8 +472,21 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 {
                     v16[c] = SAD ? q16[c] : (q16[c] + 1) >> 1;           // (S8a + S8b + S8c + S8d + 2) >> 2
                     q16[c] = 0;
-                    if (n_rect)
-                        s_quad[(q * HAD_THREADS + tid) * NC + c] = (TabT)v16[c];
+                }
+                if (RECTS)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        if ((cy >> 1) == i)
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                RQ[i][c] += v16[c];
+                        if ((cx >> 1) == i)
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                CQ[i][c] += v16[c];
+                    }
                 }
                 const int j16 = B.job[64 + q];
                 if (j16 >= 0)
@@ -431,8 +504,9 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
                 {
                     const int q32 = z >> 4;
-                    if (n_rect)
-                        rects(q32 ? B.rect_end[q32 - 1] : 0, B.rect_end[q32], s_cell, true);
+                    // (a 32x32 block with such PUs is covered completely)
+                    if (RECTS && B.rect_end[16 + q32] != B.rect_end[15 + q32])
+                        rects(B.rect_end[15 + q32], B.rect_end[16 + q32], S, T, qprev[2], qprev[1], qprev[0], v16);
                     const int j32 = B.job[80 + q32];
                     if (j32 >= 0)
                     {
@@ -449,12 +523,31 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                         a64[c] += a32[c];
                         a32[c] = 0;
                     }
+                    if (RECTS)
+                    {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                S[i][c] = T[i][c] = 0;
+                    }
+                }
+                if (RECTS)
+                {
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                    {
+                        qprev[2][c] = qprev[1][c];
+                        qprev[1][c] = qprev[0][c];
+                        qprev[0][c] = v16[c];
+                    }
                 }
             }
             z = nz;
         }
-        if (n_rect)
-            rects(B.rect_end[3], n_rect, s_quad, false);
+        // (PUs made of 16x16 values of the whole cell: the cell is covered completely)
+        if (RECTS && n_rect != B.rect_end[19])
+            rects(B.rect_end[19], n_rect, RQ, CQ, RQ[0], RQ[0], RQ[0], RQ[0]);
         const int j64 = B.job[84];
         if (j64 >= 0)
         {
@@ -509,7 +602,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             fb[(size_t)jid * fb_stride + it.slot] = f;
         }
     }
-    if (tid < n_rect)           // (bundles with rectangular PUs run with HAD_THREADS >= HIER_MAX_RECT threads)
+    if (tid < n_rect)           // (every launch has at least HAD_THREADS >= HIER_MAX_RECT threads)
     {
         unsigned long long m = ~0ull;
         for (int w = 0; w < nwaves; w++)
@@ -526,10 +619,10 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     }
 }
 
-template <typename PIX>
+template <typename PIX, bool RECTS>
 __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
-                                                          const HierItem *items, int n_items, const uint32_t *packed,
-                                                          FullBest *fb, int fb_stride)
+                                                              const HierItem *items, int n_items, const uint32_t *packed,
+                                                              FullBest *fb, int fb_stride)
 {
     extern __shared__ uint32_t lds[];
     const int id = blockIdx.x;
@@ -541,14 +634,14 @@ __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, con
     if (B.metric == X265AMD_SAD)
     {
         if (B.uniform)
-            had_item_body<PIX, false, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+            had_item_body<PIX, false, true, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
         else
-            had_item_body<PIX, true, true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+            had_item_body<PIX, true, true, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
     }
     else if (B.uniform)
-        had_item_body<PIX, false, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        had_item_body<PIX, false, false, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else
-        had_item_body<PIX, true, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        had_item_body<PIX, true, false, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
 }
 
 } // namespace xa

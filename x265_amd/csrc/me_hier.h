@@ -56,11 +56,12 @@ struct HierBundle
     int32_t  metric;            // X265AMD_SAD / X265AMD_SA8D: the jobs' integer-stage metric (me_had.h; me_hier.h is SAD only)
     uint64_t cells;             // bit z: 8x8 cell z (Z-order) is covered by some job
     int32_t  job[HIER_PUS];     // job of square k (0..63: 8x8 in Z-order, 64..79: 16x16, 80..83: 32x32, 84: 64x64), -1: none
-    // Rectangular PUs (me_had.h only), sorted by group: groups 0..3 = PUs made of 8x8 cells of 32x32 block g
-    // (mask bit = cell's Z-order index inside the block), group 4 = PUs made of whole 16x16 blocks (mask bit =
-    // the block's Z-order index inside the 64x64 cell).  rect_end[g] = end of group g in rect[].
-    int32_t  rect_end[5];
-    struct Rect { int32_t job; uint32_t mask; } rect[HIER_MAX_RECT];
+    // Rectangular PUs (me_had.h only; `kind` as had_rect_value documents, bit 31: wide keys), sorted by where they are
+    // complete: rect_end[q], q = 0..15: PUs inside 16x16 block q (Z-order); rect_end[16 + b]: PUs of 32x32 block b;
+    // rect_end[20]: PUs made of 16x16 values of the whole cell.  rect_end[g] = end of group g in rect[].
+    int32_t  rect_end[21];
+    int32_t  pad2;
+    struct Rect { int32_t job; uint32_t kind; } rect[HIER_MAX_RECT];
 };
 
 // A work item: lane tasks [t_lo, t_hi) of a bundle, in raster order of (row quad, x group)

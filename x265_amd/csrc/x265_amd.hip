@@ -100,6 +100,7 @@ struct x265amd_joblist
     int     n_hier_bundles = 0, n_hier_items = 0, hier_lds_bytes = 0;
     DevBuf  had_bundles, had_items, had_fenc;         // the same for the Hadamard exhaustive kernel
     int     n_had_bundles = 0, n_had_items = 0, had_lds_bytes = 0, had_max_depth = 10, had_threads = 128;
+    bool    had_rects = false;            // some bundle of the candidate-per-lane kernel has rectangular PUs
     DevBuf  fb_jobs;                      // with Hadamard bundles: one flag per job, "an exhaustive kernel covers its integer stage"
     bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
@@ -539,24 +540,16 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
     // (candidate-per-lane kernel: windows of more than 48 x 48 candidates are shared by 4 wavefronts instead of 2, or
     // too few wavefronts fit a CU beside each other's windows; one workgroup size per launch)
     // Workgroup size of the launch: the wavefronts that share a staged window decide how many fit a CU (measured: 4K
-    // +-16 SA8D 2.51 / 2.29 / 2.61 ms with 128 / 256 / 512 threads; 1080p 10-bit +-64 SAD 3.06 / 1.64 / 1.23 ms).  A launch
-    // with rectangular PUs keeps per-thread tables of cell values in LDS, sized for the small workgroup.
+    // +-16 SA8D 2.51 / 2.29 / 2.61 ms with 128 / 256 / 512 threads; 1080p 10-bit +-64 SAD 3.06 / 1.64 / 1.23 ms).
     int had_threads = 256;
     if (had)
     {
-        bool any_rect = false;
         for (int i = 0; i < n; i++)
-            if (had_kernel_eligible(jobs[i], bpp) && !in_bundle[i])
-            {
-                const x265amd_me_job &j = jobs[i];
-                if (j.mvmax_x - j.mvmin_x >= 48 || j.mvmax_y - j.mvmin_y >= 48)
-                    had_threads = HAD_THREADS_BIG;
-                any_rect = any_rect || j.w != j.h || (j.w & (j.w - 1)) || ((j.pu_x | j.pu_y) & (j.w - 1));
-            }
+            if (had_kernel_eligible(jobs[i], bpp) && !in_bundle[i] &&
+                (jobs[i].mvmax_x - jobs[i].mvmin_x >= 48 || jobs[i].mvmax_y - jobs[i].mvmin_y >= 48))
+                had_threads = HAD_THREADS_BIG;
         if (const char *ev = getenv("X265AMD_HAD_THREADS"))     // tuning aid: 128, 256 or 512
             had_threads = atoi(ev) >= 512 ? 512 : atoi(ev) >= 256 ? 256 : 128;
-        if (any_rect)
-            had_threads = HAD_THREADS;
     }
     if (had_threads_out)
         *had_threads_out = had_threads;
@@ -567,16 +560,42 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
     auto is_square = [](const x265amd_me_job &j, int gx, int gy) {
         return j.w == j.h && (j.w == 8 || j.w == 16 || j.w == 32 || j.w == 64) &&
                (j.pu_x - gx * 64) % j.w == 0 && (j.pu_y - gy * 64) % j.h == 0; };
-    // Another PU made of whole 8x8 cells of cell (gx, gy) (candidate-per-lane kernel)?  2: of whole aligned 16x16 blocks
-    // (the unit sa8d_inter rounds in when both sides are multiples of 16, common/pixel.cpp:313-362), 1: of 8x8 cells inside
-    // one 32x32 block (sa8d_inter rounds per 8x8), 0: neither.
-    auto rect_kind = [](const x265amd_me_job &j, int gx, int gy) {
-        const int ox = j.pu_x - gx * 64, oy = j.pu_y - gy * 64;
-        if (((j.w | j.h | ox | oy) & 7) || ox + j.w > 64 || oy + j.h > 64)
-            return 0;
-        if (((j.w | j.h) & 15) == 0)
-            return ((ox | oy) & 15) == 0 ? 2 : 0;
-        return (ox >> 5) == ((ox + j.w - 1) >> 5) && (oy >> 5) == ((oy + j.h - 1) >> 5) ? 1 : 0; };
+    // Another partition of the cell (gx, gy) the candidate-per-lane kernel derives from its running sums (had_rect_value in
+    // me_had.h)?  Returns the group it completes in (0..15: 16x16 block in Z-order, 16..19: 32x32 block, 20: whole cell) and
+    // its kind, or -1.
+    auto rect_kind = [&](const x265amd_me_job &j, int gx, int gy, int &kind) {
+        const int ox = j.pu_x - gx * 64, oy = j.pu_y - gy * 64, w = j.w, h = j.h;
+        if (((w | h | ox | oy) & 7) || ox + w > 64 || oy + h > 64)
+            return -1;
+        // halves of a 16x16 block
+        if (w == 16 && h == 8 && !(ox & 15)) { kind = (oy & 15) ? 9 : 8;  return zidx(ox >> 3, (oy & ~15) >> 3) >> 2; }
+        if (w == 8 && h == 16 && !(oy & 15)) { kind = (ox & 15) ? 11 : 10; return zidx((ox & ~15) >> 3, oy >> 3) >> 2; }
+        // strips and halves of a 32x32 block / of the cell: `unit` = 8 or 16 pixels per strip
+        for (int unit = 8; unit <= 16; unit += 8)
+        {
+            const int full = 4 * unit, rx = ox & (full - 1), ry = oy & (full - 1);
+            const int grp = unit == 8 ? 16 + (zidx(ox >> 3, oy >> 3) >> 4) : 20;
+            const int half_base = unit == 8 ? 8 : 12;       // (32x16 / 16x32 are pairs of 16x16 values; 64x32 / 32x64 pairs of strips)
+            if (w == full && rx == 0)
+            {
+                if (h == unit && ry == 0)            { kind = 0; return grp; }
+                if (h == 3 * unit && ry == unit)     { kind = 1; return grp; }
+                if (h == 3 * unit && ry == 0)        { kind = 2; return grp; }
+                if (h == unit && ry == 3 * unit)     { kind = 3; return grp; }
+                if (h == 2 * unit && ry == 0)        { kind = half_base; return grp; }
+                if (h == 2 * unit && ry == 2 * unit) { kind = half_base + 1; return grp; }
+            }
+            if (h == full && ry == 0)
+            {
+                if (w == unit && rx == 0)            { kind = 4; return grp; }
+                if (w == 3 * unit && rx == unit)     { kind = 5; return grp; }
+                if (w == 3 * unit && rx == 0)        { kind = 6; return grp; }
+                if (w == unit && rx == 3 * unit)     { kind = 7; return grp; }
+                if (w == 2 * unit && rx == 0)        { kind = half_base + 2; return grp; }
+                if (w == 2 * unit && rx == 2 * unit) { kind = half_base + 3; return grp; }
+            }
+        }
+        return -1; };
     std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < n; i++)
     {
@@ -584,7 +603,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if (!(had ? had_kernel_eligible(j, bpp) : full_kernel_eligible(j, bpp)) || in_bundle[i])
             continue;
         const int gx = fl(j.pu_x), gy = fl(j.pu_y);
-        if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy)))
+        int kind_unused;
+        if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy, kind_unused) >= 0))
             continue;
         groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
     }
@@ -598,7 +618,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
         double old_work = 0;
         std::vector<int> taken;
-        std::vector<HierBundle::Rect> rects[5];
+        std::vector<HierBundle::Rect> rects[21];
         for (int i : g.second)
         {
             const x265amd_me_job &j = jobs[i];
@@ -617,16 +637,19 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                     total += r.size();
                 if (total >= (size_t)HIER_MAX_RECT)
                     continue;
-                HierBundle::Rect r = { i, 0u };
-                const bool quads = rect_kind(j, gx, gy) == 2;
-                for (int yy = 0; yy < (j.h >> 3); yy++)
-                    for (int xx = 0; xx < (j.w >> 3); xx++)
-                        r.mask |= 1u << (quads ? zidx(cx + xx, cy + yy) >> 2 : zidx(cx + xx, cy + yy) & 15);
+                int kind = 0;
+                const int grp = rect_kind(j, gx, gy, kind);
+                HierBundle::Rect r = { i, (uint32_t)kind };
                 // (32-bit keys hold costs below 2^21: bound the PU's cost by its 8x8 cells' worst case plus the largest MV cost)
                 const double cell_max = j.icost == X265AMD_SA8D ? 131072.0 : 64.0 * (bpp == 1 ? 255.0 : 4095.0);
                 if ((j.w >> 3) * (j.h >> 3) * cell_max + HIER_MVCOST_MAX >= (double)(1 << 21))
-                    r.mask |= 0x80000000u;
-                rects[quads ? 4 : z >> 4].push_back(r);
+                    r.kind |= 0x80000000u;
+                rects[grp].push_back(r);
+                // the running sums need every cell of the 16x16 block / 32x32 block / cell the PU belongs to
+                const int span = grp < 16 ? 2 : grp < 20 ? 4 : 8, bx = cx & ~(span - 1), by = cy & ~(span - 1);
+                for (int yy = 0; yy < span; yy++)
+                    for (int xx = 0; xx < span; xx++)
+                        B.cells |= 1ull << zidx(bx + xx, by + yy);
             }
             taken.push_back(i);
             for (int yy = 0; yy < (j.h >> 3); yy++)
@@ -659,7 +682,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
         B.metric = j0.icost;
         int n_rect = 0;
-        for (int gk = 0; gk < 5; gk++)
+        for (int gk = 0; gk < 21; gk++)
         {
             for (const HierBundle::Rect &r : rects[gk])
                 B.rect[n_rect++] = r;
@@ -693,7 +716,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
         const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
-                          (n_rect ? 8 * (HAD_THREADS / 64) * HIER_MAX_RECT + 2 * 16 * HAD_THREADS * NC * (had_sad && bpp == 1 ? 2 : 4) : 0);
+                          (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0);
         bool fits = true;
         std::vector<HierItem> mine;
         for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
@@ -718,6 +741,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             in_bundle[i] = 1;
         bundles.push_back(B);
         items.insert(items.end(), mine.begin(), mine.end());
+        if (n_rect && had_threads_out)
+            *had_threads_out |= 1 << 16;        // (bit 16: some bundle has rectangular PUs)
     }
     if (bundles.empty())
         lds_bytes = 0;
@@ -772,6 +797,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     const std::vector<char> in_hier = in_bundle;
     if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the candidate-per-lane kernel off)
         plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes, &L->had_threads);
+    L->had_rects = (L->had_threads >> 16) != 0;
+    L->had_threads &= 0xffff;
     if (!ditems.empty())
     {
         xcd_interleave(ditems);
@@ -936,10 +963,16 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
 #define XA_LAUNCH_HAD(PIX)                                                                                         \
         hipLaunchKernelGGL(k_pack_fenc16<PIX>, dim3(L->n_had_bundles), dim3(256), 0, st, P,                        \
                            (const HierBundle*)L->had_bundles.p, L->n_had_bundles, (uint32_t*)L->had_fenc.p);       \
-        hipLaunchKernelGGL(k_full_had<PIX>, dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P,      \
-                           (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,                  \
-                           (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,        \
-                           (FullBest*)L->fb.p, FB_STRIDE_PLAN)
+        if (L->had_rects)                                                                                          \
+            hipLaunchKernelGGL((k_full_had<PIX, true>), dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P, \
+                               (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,              \
+                               (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,    \
+                               (FullBest*)L->fb.p, FB_STRIDE_PLAN);                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_full_had<PIX, false>), dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P, \
+                               (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,              \
+                               (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,    \
+                               (FullBest*)L->fb.p, FB_STRIDE_PLAN)
         if (L->bpp == 1) { XA_LAUNCH_HAD(uint8_t); } else { XA_LAUNCH_HAD(uint16_t); }
 #undef XA_LAUNCH_HAD
         HIPCHK(c, hipGetLastError());
