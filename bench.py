@@ -462,6 +462,37 @@ def main():
                                            "search_kernel_ms": k_had_tail_ms, "algorithmic_ops_per_launch": had_ops,
                                            "ops_def": "SA8D evaluation = 7*w*h integer operations; algorithmic = every PU's candidates x its "
                                                       "own pixels (the kernel prices each 8x8 cell once for the four levels, so frac can exceed 1)"}}
+    # the same frame with EVERY partition of the CTUs that is made of 8x8 cells (85 squares + 124 symmetric / asymmetric
+    # rectangles per CTU) in one list: one pass over each window prices them all
+    parts = [had_jobs]
+    for n2 in (16, 32, 64):
+        q4 = n2 // 4
+        shapes = [(0, 0, n2, n2 // 2), (0, n2 // 2, n2, n2 // 2), (0, 0, n2 // 2, n2), (n2 // 2, 0, n2 // 2, n2)]
+        if n2 > 16:
+            shapes += [(0, 0, n2, q4), (0, q4, n2, n2 - q4), (0, 0, n2, n2 - q4), (0, n2 - q4, n2, q4),
+                       (0, 0, q4, n2), (q4, 0, n2 - q4, n2), (0, 0, n2 - q4, n2), (n2 - q4, 0, q4, n2)]
+        cy4, cx4 = np.mgrid[0:H4 - n2 + 1:n2, 0:W4 - n2 + 1:n2]
+        for (ox, oy, w, h) in shapes:
+            parts.append(J.make_jobs(W4, H4, cx4.ravel() + ox, cy4.ravel() + oy, w, h, method=J.FULL, subme=0, merange=16, qp=27,
+                                     icost=J.SA8D))
+    all_jobs = np.concatenate(parts)
+    jl_all = eng.make_joblist(all_jobs, bytes_per_px=2)
+    for _ in range(2):
+        jl_all.run(ids4[1], [ids4[0]], fetch=False)
+    eng.sync()
+    eng.eval_count(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        jl_all.run(ids4[1], [ids4[0]], fetch=False)
+    eng.sync()
+    all_dt = (time.perf_counter() - t0) / 5
+    all_evals = eng.eval_count() / 5
+    k_all_ms, k_all_tail_ms = eng.kernel_times()
+    all_res = jl_all.results()
+    jl_all.close()
+    line["sa8d_full_4k10"]["all_partitions"] = {"jobs_per_frame": int(len(all_jobs)), "evals_per_frame": all_evals,
+                                                "value": all_evals / all_dt, "unit": "evals/s", "ms_per_frame": all_dt * 1e3,
+                                                "kernel_ms": k_all_ms, "search_kernel_ms": k_all_tail_ms}
     for i in ids4:
         eng.release_plane(i)
 
@@ -505,7 +536,10 @@ def main():
         ok = ok and bool(np.array_equal(chk, full_res[fsel]))
         hsel = np.arange(0, len(had_jobs), 997)
         chk, _ = o.search(seq4[1], [seq4[0]], had_jobs[hsel], threads=8, bit_depth=10)
-        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, had_res[hsel]))
+        ok = ok and bool(np.array_equal(chk, had_res[hsel]))
+        asel = np.arange(len(had_jobs), len(all_jobs), 2503)
+        chk, _ = o.search(seq4[1], [seq4[0]], all_jobs[asel], threads=8, bit_depth=10)
+        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, all_res[asel]))
 
     print(json.dumps(line), flush=True)
 

@@ -16,6 +16,10 @@ if "sa8d_full_4k10" in d:
     s = d["sa8d_full_4k10"]
     print("sa8d 4K 10-bit: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms" %
           (s["value"], s["ms_per_frame"], s["roofline"]["kernel_ms"], s["roofline"]["search_kernel_ms"]))
+    if "all_partitions" in s:
+        a = s["all_partitions"]
+        print("  all %d partitions: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms" %
+              (a["jobs_per_frame"], a["value"], a["ms_per_frame"], a["kernel_ms"], a["search_kernel_ms"]))
 if "lookahead" in d:
     l = d["lookahead"]
     print("lookahead: %d pairs %.3f ms  (%.0f pairs/s, %.4g evals/s)  single pair %.3f ms  lowres init %.1f us  cpu %s  parity %s" %
