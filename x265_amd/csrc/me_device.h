@@ -828,7 +828,7 @@ struct Dev
     // SADs of n candidates of a PU of at most 16 groups: candidate c0 + row in 16-lane row `row`;
     // lane k of `res` receives the SAD of candidate k.
     template <bool LW>
-    static __device__ __forceinline__ void sad_rows(const View &v, const Src &src, int pitch, int n, int &res)
+    static __device__ __forceinline__ void sad_rows(const View &v, const Src &src, int pitch, int n, int cflags, int &res)
     {
         const int row = v.lane >> 4, gl = v.lane & 15;
         const bool in_pu = gl < v.G;
@@ -844,6 +844,8 @@ struct Dev
             const int off = v.s->pts[k < n ? k : 0];
             uint32_t r[2];
             src.template rd4_packed<LW>(off + lo, r);
+            if (c0 == 0)
+                res += label_cost(v, n, cflags);        // (its LDS look-ups run while the pixel reads are in flight)
             int sad;
             if (DW == 1)
                 sad = __builtin_amdgcn_sad_u8(f[0], r[0], 0);
@@ -1056,24 +1058,24 @@ struct Dev
         const bool lw = L::USE_WIN && (cflags & CF_WINDOW) != 0;
         const int pitch = lw ? v.s->wpitch : v.s->stride;
         Src src(v, lw);
-        const int mv = label_cost(v, n, cflags);
         const int par = (cflags & CF_PAR) ? 1 : 0;
-        int p[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            p[k] = v.s->pts[k];             // (entries >= n repeat candidate 0)
         if (NW == 1 && n > 1 && v.G <= 16)
         {
             // small PU (8x8 and below) on its own wavefront: four candidates side by side, one per 16-lane row
-            int res = mv;
-            if (lw) sad_rows<true>(v, src, pitch, n, res);
-            else    sad_rows<false>(v, src, pitch, n, res);
+            int res = 0;
+            if (lw) sad_rows<true>(v, src, pitch, n, cflags, res);
+            else    sad_rows<false>(v, src, pitch, n, cflags, res);
             Res8 r;
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 r.c[k] = __builtin_amdgcn_readlane(res, k);
             return r;
         }
+        const int mv = label_cost(v, n, cflags);
+        int p[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            p[k] = v.s->pts[k];             // (entries >= n repeat candidate 0)
         int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (n == 1)
         {
@@ -1176,7 +1178,7 @@ struct Dev
     // The same for PUs of at most 16 groups on a single wavefront (8x8 and smaller: the lookahead's
     // CUs): the PU occupies one 16-lane row, so four candidates are priced side by side, one per row,
     // instead of one after the other in the same lanes.
-    static __device__ __forceinline__ void lr_batch_rows(View &v, const Src &src, int kind, int n, int &res)
+    static __device__ __forceinline__ void lr_batch_rows(View &v, const Src &src, int kind, int n, int cflags, int &res)
     {
         const int w = uni(v.s->w), h = uni(v.s->h), pitch = v.s->stride, step_lr = v.s->lrstep;
         const int am = accum_mode(kind, w, h);
@@ -1199,6 +1201,8 @@ struct Dev
             uint32_t a[2], b[2];
             src.rd4_plane(off + lo, (fr & 3) * step_lr, a);
             src.rd4_plane(offb + lo, (avg ? (fr >> 2) & 3 : fr & 3) * step_lr, b);
+            if (c0 == 0)
+                res += label_cost(v, n, cflags);        // (its LDS look-ups run while the plane reads are in flight)
             P4 r;
             if (DW == 1)
             {
@@ -1337,15 +1341,30 @@ struct Dev
 #ifdef XA_PROFILE
         v.s->cpt[0] = (long long)__builtin_readcyclecounter();
 #endif
-        int res = label_cost(v, n, cflags);     // lane k collects candidate k
         int par = (cflags & CF_PAR) ? 1 : 0;
+        if (L::LR && NW == 1 && v.G <= 16 && (uni(v.s->frc[0]) & LR_FLAG))
+        {
+            int res = 0;                        // lane k collects candidate k
+#ifdef XA_PROFILE
+            v.s->cpt[1] = v.s->cpt[0];
+#endif
+            lr_batch_rows(v, src, kind, n, cflags, res);
+            Res8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                r.c[k] = __builtin_amdgcn_readlane(res, k);
+#ifdef XA_PROFILE
+            v.s->cpt[3] = (long long)__builtin_readcyclecounter() + (r.c[0] & 0);
+#endif
+            return r;
+        }
+        int res = label_cost(v, n, cflags);     // lane k collects candidate k
         if (L::LR && (uni(v.s->frc[0]) & LR_FLAG))
         {
 #ifdef XA_PROFILE
             v.s->cpt[1] = (long long)__builtin_readcyclecounter() + (__builtin_amdgcn_readfirstlane(res) & 0);
 #endif
-            if (NW == 1 && v.G <= 16) lr_batch_rows(v, src, kind, n, res);
-            else if (n == 1) lr_batch<1>(v, src, kind, par, res);
+            if (n == 1) lr_batch<1>(v, src, kind, par, res);
             else if (n <= 4) lr_batch<4>(v, src, kind, par, res);
             else             lr_batch<8>(v, src, kind, par, res);
             Res8 r;
