@@ -1051,7 +1051,22 @@ struct Dev
     //
     // eval_sad: full-pel SADs, all candidates in one pass over the PU, like the sad / sad_x3 /
     // sad_x4 primitives (common/pixel.cpp:78-142).
-    static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_)
+    // (out of line for the general kernels, whose body must keep to uniform control flow; the single-wavefront kernels
+    // for half-resolution references are latency-bound chains and take the same code inline: call_sad / call_any)
+    static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_) { return eval_sad_body(base, n_, cflags_); }
+    static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_) { return eval_any_body(base, n_, cflags_, kind_); }
+    static constexpr bool INLINE_EVAL = L::LR && NW == 1;
+    static __device__ __forceinline__ Res8 call_sad(uint32_t base, int n, int cflags)
+    {
+        if constexpr (INLINE_EVAL) return eval_sad_body(base, n, cflags);
+        else                       return eval_sad(base, n, cflags);
+    }
+    static __device__ __forceinline__ Res8 call_any(uint32_t base, int n, int cflags, int kind)
+    {
+        if constexpr (INLINE_EVAL) return eval_any_body(base, n, cflags, kind);
+        else                       return eval_any(base, n, cflags, kind);
+    }
+    static __device__ __forceinline__ Res8 eval_sad_body(uint32_t base, int n_, int cflags_)
     {
         const int n = uni(n_), cflags = uni(cflags_);
         View v(base);
@@ -1331,7 +1346,7 @@ struct Dev
 
     // eval_any: any cost kind, each candidate with its own phase (JobState::frc), one cost_body per
     // candidate (half-resolution reference sets: one batch, lr_batch).
-    static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_)
+    static __device__ __forceinline__ Res8 eval_any_body(uint32_t base, int n_, int cflags_, int kind_)
     {
         const int n = uni(n_), cflags = uni(cflags_), kind = uni(kind_);
         View v(base);
@@ -1621,7 +1636,7 @@ struct Wave
         {
             const int cf = where | cflags | take_par(1);
             D::post(base, D::OP_SAD, n, cf);
-            r = D::eval_sad(base, n, cf);
+            r = D::call_sad(base, n, cf);
         }
         else
         {
@@ -1637,7 +1652,7 @@ struct Wave
 #ifdef XA_PROFILE
             const long long t_b = (long long)__builtin_readcyclecounter();
 #endif
-            r = D::eval_any(base, n, cf, kind);
+            r = D::call_any(base, n, cf, kind);
 #ifdef XA_PROFILE
             if (frac && lowres)
             {

@@ -563,7 +563,7 @@ struct Search
         W.evals += (unsigned)n;
         const int cf = where | W.take_par(W.lowres ? 1 : n);
         D::post(W.base, D::OP_ANY, n, cf, kind);
-        const Res8 r = D::eval_any(W.base, n, cf, kind);
+        const Res8 r = D::call_any(W.base, n, cf, kind);
         int bdir = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++)
