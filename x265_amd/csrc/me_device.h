@@ -245,12 +245,13 @@ struct JobState
 // LDS of one job: NW waves, PUs of up to MAXG 4-pixel groups (MAXG = 1024 covers 64x64).
 // LR: the kernel also handles half-resolution reference sets (PlaneDesc::lr_step != 0); kernels
 // built without it are leaner and must not be given such references.
-template <typename PIX_, int NW_, int MAXG_, bool LR_ = false>
+// INL: a single-wavefront kernel that takes the evaluation code inline instead of calling it (latency-bound chains).
+template <typename PIX_, int NW_, int MAXG_, bool LR_ = false, bool INL_ = false>
 struct JobLds
 {
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
-    static constexpr bool LR = LR_;
+    static constexpr bool LR = LR_, INL = INL_;
     // A window of the reference plane around the search centre is kept in LDS only by the class of the largest PUs:
     // measured on MI355X, staging it costs the smaller classes more instructions than reading candidates from the
     // plane (L2) does (8x8 .. 32x32 PUs: 3 - 14 % faster without, 64x64: 6 - 16 % slower without).
@@ -1055,7 +1056,7 @@ struct Dev
     // for half-resolution references are latency-bound chains and take the same code inline: call_sad / call_any)
     static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_) { return eval_sad_body(base, n_, cflags_); }
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_) { return eval_any_body(base, n_, cflags_, kind_); }
-    static constexpr bool INLINE_EVAL = L::LR && NW == 1;
+    static constexpr bool INLINE_EVAL = NW == 1 && (L::LR || L::INL);
     static __device__ __forceinline__ Res8 call_sad(uint32_t base, int n, int cflags)
     {
         if constexpr (INLINE_EVAL) return eval_sad_body(base, n, cflags);

@@ -1600,7 +1600,7 @@ template <typename PIX>
 void launch_field(x265amd_ctx *c, int cls, int n_fields, int gh, const uint16_t *cost, int pu_w, int pu_h, int gw,
                   int pic_w, int pic_h, int merange, int method, int subme, int qp, x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false>>), dim3(n_fields * gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_fields * gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
                                               (const LookPair*)c->look_pairs.p, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
