@@ -381,55 +381,51 @@ struct Search
         const bool sub = ((pmx | pmy) & 3) != 0, nz = pmx || pmy;
         bmx = XA_S16(XA_S16(pmx + 2) >> 2);
         bmy = XA_S16(XA_S16(pmy + 2) >> 2);
-        // dense candidate list (static indices only: everything stays in scalar registers)
-        int qx[8], qy[8], n = 0;
+        // fixed slots (static indices only: everything stays in scalar registers): 0 the predictor, 1 its rounded
+        // position, 2 the zero vector, 3.. the candidates; a slot that is not wanted repeats the predictor and its cost
+        // is ignored (the usual 5 to 7 candidates are two passes of the side-by-side forms either way)
+        static_assert(X265AMD_MAX_MVC <= 4, "eight slots");
+        int qx[8], qy[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            qx[k] = qy[k] = 0;
-        auto push = [&](bool use, int x, int y)
         {
-            int at = -1;
-            if (use)
-            {
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (n == k)
-                    {
-                        qx[k] = x;
-                        qy[k] = y;
-                    }
-                at = n++;
-            }
-            return at;
-        };
-        push(true, pmx, pmy);
-        const int k_round = push(sub, XA_S16(bmx << 2), XA_S16(bmy << 2));
-        const int k_zero = push(nz, 0, 0);
-        int cmx[X265AMD_MAX_MVC], cmy[X265AMD_MAX_MVC], k_mvc[X265AMD_MAX_MVC];
+            qx[k] = pmx;
+            qy[k] = pmy;
+        }
+        if (sub)
+        {
+            qx[1] = XA_S16(bmx << 2);
+            qy[1] = XA_S16(bmy << 2);
+        }
+        if (nz)
+            qx[2] = qy[2] = 0;
+        int cmx[X265AMD_MAX_MVC], cmy[X265AMD_MAX_MVC];
+        bool use[X265AMD_MAX_MVC];
+        int wanted = 1 + (sub ? 1 : 0) + (nz ? 1 : 0), ns = nz ? 3 : sub ? 2 : 1;     // slots in use: up to the last wanted one
 #pragma unroll
         for (int i = 0; i < X265AMD_MAX_MVC; i++)
         {
             cmx[i] = clipq(j.mvc[i][0], qminx, qmaxx);
             cmy[i] = clipq(j.mvc[i][1], qminy, qmaxy);
-            k_mvc[i] = push(i < j.numc && (cmx[i] || cmy[i]) && !(cmx[i] == pmx && cmy[i] == pmy), cmx[i], cmy[i]);
+            use[i] = i < j.numc && (cmx[i] || cmy[i]) && !(cmx[i] == pmx && cmy[i] == pmy);
+            if (use[i])
+            {
+                qx[3 + i] = cmx[i];
+                qy[3 + i] = cmy[i];
+                wanted++;
+                ns = 4 + i;
+            }
         }
         int c[8];
-        W.subpel_cost8(n, qx, qy, W.ikind, c, CF_NOMV0);      // the predictor itself carries no MV cost (motion.cpp:305)
-        auto at = [&](int k)
-        {
-            int r = c[0];
-#pragma unroll
-            for (int i = 1; i < 8; i++)
-                r = (k == i) ? c[i] : r;
-            return r;
-        };
+        W.subpel_cost8(ns, qx, qy, W.ikind, c, CF_NOMV0);     // the predictor itself carries no MV cost (motion.cpp:305)
+        W.evals -= (unsigned)(ns - wanted);
         int bprecost = c[0];
         bcost = bprecost;
         if (sub)
-            bcost = at(k_round);
+            bcost = c[1];
         if (nz)
         {
-            const int cz = at(k_zero);
+            const int cz = c[2];
             if (cz < bcost)
             {
                 bcost = cz;
@@ -439,14 +435,14 @@ struct Search
 #pragma unroll
         for (int i = 0; i < X265AMD_MAX_MVC; i++)
         {
-            if (k_mvc[i] < 0)
+            if (!use[i])
                 continue;
             if (cmx[i] == bprex && cmy[i] == bprey)
             {
                 W.evals--;              // the reference skips a candidate equal to the best so far (motion.cpp:325)
                 continue;
             }
-            const int cc = at(k_mvc[i]);
+            const int cc = c[3 + i];
             if (cc < bprecost)
             {
                 bprecost = cc;
@@ -552,9 +548,12 @@ struct Search
         // every candidate's block origin lies within [(bmv - step) >> 2, (bmv + step) >> 2]
         const int where = W.lowres ? 0 : W.place(XA_S16(bmx - step) >> 2, XA_S16(bmy - step) >> 2,
                                                  XA_S16(bmx + step) >> 2, XA_S16(bmy + step) >> 2, true);
+        // (only the first n entries: every evaluation path reads candidates below n, or repeats candidate 0)
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
+            if (k >= 4 && n <= 4)
+                break;
             const int qx = XA_S16(bmx + c_square1[k + 1][0] * step), qy = XA_S16(bmy + c_square1[k + 1][1] * step);
             W.s->pts[k] = W.block_off(where, qx >> 2, qy >> 2);
             W.s->lbl[k] = (qy << 16) | (qx & 0xffff);
