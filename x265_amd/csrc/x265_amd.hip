@@ -303,7 +303,7 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
     if (cnt[2] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 256, LR>>), dim3(cnt[1]), dim3(256), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, true>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, true>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
 }
