@@ -48,7 +48,7 @@ struct PlaneDesc
 
 struct P4 { int v[4]; };
 
-__constant__ int c_luma[4][8] = {   // HEVC luma taps, Lib/TLibCommon/TComRom.cpp:176-182
+static __constant__ int c_luma[4][8] = {   // HEVC luma taps, Lib/TLibCommon/TComRom.cpp:176-182
     {  0, 0,   0, 64,  0,   0, 0,  0 },
     { -1, 4, -10, 58, 17,  -5, 1,  0 },
     { -1, 4, -11, 40, 40, -11, 4, -1 },
@@ -58,12 +58,12 @@ __constant__ int c_luma[4][8] = {   // HEVC luma taps, Lib/TLibCommon/TComRom.cp
 // and two signed 16-bit values per dword (taps 0-1, 2-3, 4-5, 6-7)
 #define XA_B4(a, b, c, d) (int)(((a) & 0xffu) | (((b) & 0xffu) << 8) | (((c) & 0xffu) << 16) | (((unsigned)(d) & 0xffu) << 24))
 #define XA_H2(a, b) (int)(((a) & 0xffffu) | ((unsigned)(b) << 16))
-__constant__ int c_luma_b4[4][2] = {
+static __constant__ int c_luma_b4[4][2] = {
     { XA_B4(0, 0, 0, 64),   XA_B4(0, 0, 0, 0) },
     { XA_B4(-1, 4, -10, 58), XA_B4(17, -5, 1, 0) },
     { XA_B4(-1, 4, -11, 40), XA_B4(40, -11, 4, -1) },
     { XA_B4(0, 1, -5, 17),  XA_B4(58, -10, 4, -1) } };
-__constant__ int c_luma_h2[4][4] = {
+static __constant__ int c_luma_h2[4][4] = {
     { XA_H2(0, 0),  XA_H2(0, 64),   XA_H2(0, 0),   XA_H2(0, 0) },
     { XA_H2(-1, 4), XA_H2(-10, 58), XA_H2(17, -5), XA_H2(1, 0) },
     { XA_H2(-1, 4), XA_H2(-11, 40), XA_H2(40, -11), XA_H2(4, -1) },
@@ -1056,7 +1056,7 @@ struct Dev
     // for half-resolution references are latency-bound chains and take the same code inline: call_sad / call_any)
     static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_) { return eval_sad_body(base, n_, cflags_); }
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_) { return eval_any_body(base, n_, cflags_, kind_); }
-    static constexpr bool INLINE_EVAL = NW == 1 && (L::LR || L::INL);
+    static constexpr bool INLINE_EVAL = NW == 1 && L::INL;
     static __device__ __forceinline__ Res8 call_sad(uint32_t base, int n, int cflags)
     {
         if constexpr (INLINE_EVAL) return eval_sad_body(base, n, cflags);

@@ -7,6 +7,11 @@
 #include "me_lowres.h"
 #include "me_field.h"
 
+// (the general search, field and lookahead kernels are instantiated in x265_amd_part.hip)
+#define XA_INST extern template
+#include "x265_amd_inst.h"
+#undef XA_INST
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -303,9 +308,9 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
     if (cnt[2] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, true>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, true>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
 }
 
 int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
@@ -1565,11 +1570,11 @@ int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, con
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
     const dim3 grid(n_pairs * cu_h), block(64);
     if (first->bpp == 1)
-        hipLaunchKernelGGL((k_lookahead<JobLds<uint8_t, 1, 64, true>>), grid, block, 0, c->stream, c->d_planes, cost,
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint8_t, 1, 64, true, true>>), grid, block, 0, c->stream, c->d_planes, cost,
                            (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
                            (x265amd_me_result*)c->look_results.p, error, c->d_evals);
     else
-        hipLaunchKernelGGL((k_lookahead<JobLds<uint16_t, 1, 64, true>>), grid, block, 0, c->stream, c->d_planes, cost,
+        hipLaunchKernelGGL((k_lookahead<JobLds<uint16_t, 1, 64, true, true>>), grid, block, 0, c->stream, c->d_planes, cost,
                            (const LookPair*)c->look_pairs.p, cu_w, cu_h, merange, method, subme, qp, c->flags,
                            (x265amd_me_result*)c->look_results.p, error, c->d_evals);
     HIPCHK(c, hipGetLastError());
