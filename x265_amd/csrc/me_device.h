@@ -1056,7 +1056,7 @@ struct Dev
     // for half-resolution references are latency-bound chains and take the same code inline: call_sad / call_any)
     static __device__ __noinline__ Res8 eval_sad(uint32_t base, int n_, int cflags_) { return eval_sad_body(base, n_, cflags_); }
     static __device__ __noinline__ Res8 eval_any(uint32_t base, int n_, int cflags_, int kind_) { return eval_any_body(base, n_, cflags_, kind_); }
-    static constexpr bool INLINE_EVAL = NW == 1 && L::INL;
+    static constexpr bool INLINE_EVAL = L::INL;
     static __device__ __forceinline__ Res8 call_sad(uint32_t base, int n, int cflags)
     {
         if constexpr (INLINE_EVAL) return eval_sad_body(base, n, cflags);
@@ -1487,6 +1487,7 @@ struct Wave
     unsigned evals;
 #ifdef XA_PROFILE                   // developer aid: shader-clock stamps at phase boundaries of the search
     long long tstamp[8];
+    long long cgen[6] = { 0, 0, 0, 0, 0, 0 };          // eval_n: SAD calls {count, set-up, call}, other calls {count, set-up, call}
     long long cprof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // eval_any calls: count, set-up, call -> entry, MV costs, pixel work, reduce, return, unpack
     __device__ __forceinline__ void stamp(int k) { tstamp[k] = (long long)__builtin_readcyclecounter(); }
 #else
@@ -1636,8 +1637,15 @@ struct Wave
         if (multi)
         {
             const int cf = where | cflags | take_par(1);
+#ifdef XA_PROFILE
+            const long long t_b = (long long)__builtin_readcyclecounter();
+#endif
             D::post(base, D::OP_SAD, n, cf);
             r = D::call_sad(base, n, cf);
+#ifdef XA_PROFILE
+            const long long t_c = (long long)__builtin_readcyclecounter() + (uni(r.c[0]) & 0);
+            cgen[0] += 1; cgen[1] += t_b - t_a; cgen[2] += t_c - t_b;
+#endif
         }
         else
         {
@@ -1655,6 +1663,10 @@ struct Wave
 #endif
             r = D::call_any(base, n, cf, kind);
 #ifdef XA_PROFILE
+            {
+                const long long t_c = (long long)__builtin_readcyclecounter() + (uni(r.c[0]) & 0);
+                cgen[3] += 1; cgen[4] += t_b - t_a; cgen[5] += t_c - t_b;
+            }
             if (frac && lowres)
             {
                 const long long t_c = (long long)__builtin_readcyclecounter() + (uni(r.c[0]) & 0);

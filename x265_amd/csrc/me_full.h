@@ -25,7 +25,7 @@
 namespace xa {
 
 #ifdef XA_PROFILE
-__device__ unsigned long long g_full_prof[8];     // developer aid: clocks {workgroup total, staging, job staging, scan}, items
+static __device__ unsigned long long g_full_prof[8];     // developer aid: clocks {workgroup total, staging, job staging, scan}, items
 #define XA_TICK() ((long long)__builtin_readcyclecounter())
 #endif
 constexpr int FULL_THREADS = 256;

@@ -54,7 +54,7 @@ constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
 
 template <class L>
-__global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,
+__global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::NW == 1 && L::INL ? 8 : 1))) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,
                                                   const FullBest *fb, int fb_stride, x265amd_me_result *out,
                                                   unsigned long long *evals)
 {
@@ -90,6 +90,9 @@ __global__ void __launch_bounds__(L::NT) k_search(BatchParams P, const x265amd_m
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)      // (a sample: every job would serialise on the atomics)
         for (int k = 0; k < 6; k++)
             atomicAdd(evals + EVAL_SLOTS * 16 + k, (unsigned long long)(W.tstamp[k + 1] - W.tstamp[k]));
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
+        for (int k = 0; k < 6; k++)
+            atomicAdd(evals + (EVAL_SLOTS + 1) * 16 + 8 + k, (unsigned long long)W.cgen[k]);
 #endif
 }
 

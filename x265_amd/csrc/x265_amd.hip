@@ -306,7 +306,7 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
     // the large PUs first: they are the long-running workgroups
     int k = 0;
     if (cnt[2] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR, !LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
@@ -2117,6 +2117,9 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
             fprintf(stderr, "half-resolution sub-pel calls (sampled rows): %llu calls; clocks per call: set-up %llu  call -> entry %llu  MV costs %llu  "
                             "plane reads %llu  reduce %llu  return %llu  unpack %llu\n", cq[0], cq[1] / cq[0], cq[2] / cq[0], cq[3] / cq[0],
                     cq[4] / cq[0], cq[5] / cq[0], cq[6] / cq[0], cq[7] / cq[0]);
+        if (cq[8] || cq[11])
+            fprintf(stderr, "evaluation calls (sampled jobs): SAD %llu calls, set-up %llu + call %llu clocks each; other %llu calls, set-up %llu + call %llu clocks each\n",
+                    cq[8], cq[9] / (cq[8] ? cq[8] : 1), cq[10] / (cq[8] ? cq[8] : 1), cq[11], cq[12] / (cq[11] ? cq[11] : 1), cq[13] / (cq[11] ? cq[11] : 1));
         unsigned long long fp[8], zero[8] = { 0 };
         HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_full_prof), sizeof(fp)));
         if (fp[4])

@@ -7,7 +7,7 @@
                                                                            int, int, const xa::FullBest*, int,           \
                                                                            x265amd_me_result*, unsigned long long*);
 #define XA_K_SEARCH_PIX(PIX)                                                                                             \
-    XA_K_SEARCH(PIX, 8, 1024, false, false) XA_K_SEARCH(PIX, 1, 256, false, true) XA_K_SEARCH(PIX, 1, 64, false, true)    \
+    XA_K_SEARCH(PIX, 8, 1024, false, true) XA_K_SEARCH(PIX, 1, 256, false, true) XA_K_SEARCH(PIX, 1, 64, false, true)    \
     XA_K_SEARCH(PIX, 8, 1024, true, false)  XA_K_SEARCH(PIX, 1, 256, true, false) XA_K_SEARCH(PIX, 1, 64, true, false)
 #define XA_K_FIELD(PIX, NW, MAXG)                                                                                        \
     XA_INST __global__ void xa::k_field<xa::JobLds<PIX, NW, MAXG, false, NW == 1>>(const xa::PlaneDesc*, const uint16_t*, \
