@@ -113,17 +113,19 @@ template <typename PIX> struct PixTraits;
 template <> struct PixTraits<uint8_t>  { static constexpr int DW = 1; };   // dwords per 4-pixel group
 template <> struct PixTraits<uint16_t> { static constexpr int DW = 2; };
 
+// Byte-aligned dword / qword loads of plane memory (gfx950 allows them).  The pointer is cast to the
+// global address space: a generic pointer would make these FLAT loads, whose results are waited for
+// on the LDS counter as well as the memory counter.
+#define XA_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ uint32_t ld_u32(const void *p)
 {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);   // byte-aligned dword load (global memory allows it on gfx950)
-    return v;
+    struct __attribute__((packed)) U { uint32_t v; };
+    return ((const XA_GLOBAL U*)(uintptr_t)p)->v;
 }
 __device__ __forceinline__ uint64_t ld_u64(const void *p)
 {
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+    struct __attribute__((packed)) U { uint64_t v; };
+    return ((const XA_GLOBAL U*)(uintptr_t)p)->v;
 }
 
 __device__ __forceinline__ P4 load4(const uint8_t *p)
@@ -779,13 +781,30 @@ struct Dev
         const int stride = uni(v.s->stride), gLo = uni(v.s->gLo), gHi = uni(v.s->gHi);
         const PIX *refbase = (const PIX*)uni64(v.s->refbase);
         const int n = pdw * wh;
-        for (int i = v.tid; i < n; i += NT)
+        // every lane's loads are issued before the first is stored (one memory round trip per restage);
+        // row = i / pdw by multiplication: exact for i * pdw < 2^32
+        constexpr int IT = (L::WIN_BYTES / 4 + NT - 1) / NT;
+        const uint32_t magic = 0xffffffffu / (uint32_t)pdw + 1;
+        uint32_t d[IT > 0 ? IT : 1];
+#pragma unroll
+        for (int k = 0; k < IT; k++)
         {
-            int r = i / pdw, c = i - r * pdw;
-            int o = (wy0 + r) * stride + wx0 + c * (4 / PB);
-            o = o < gLo ? gLo : o;
-            o = o > gHi - 4 / PB ? gHi - 4 / PB : o;
-            v.l->win[i] = ld_u32(refbase + o);
+            const int i = v.tid + k * NT;
+            if (i < n)
+            {
+                const int r = (int)__umulhi((uint32_t)i, magic), c = i - r * pdw;
+                int o = (wy0 + r) * stride + wx0 + c * (4 / PB);
+                o = o < gLo ? gLo : o;
+                o = o > gHi - 4 / PB ? gHi - 4 / PB : o;
+                d[k] = ld_u32(refbase + o);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++)
+        {
+            const int i = v.tid + k * NT;
+            if (i < n)
+                v.l->win[i] = d[k];
         }
         bsync();
         return 1;
@@ -1036,7 +1055,7 @@ struct Dev
         {
             const int lb = v.s->lbl[v.lane];
             const int dx = (int16_t)((int16_t)lb - v.s->mvpx), dy = (int16_t)((lb >> 16) - v.s->mvpy);
-            const uint16_t *tab = (const uint16_t*)v.s->cost;
+            const XA_GLOBAL uint16_t *tab = (const XA_GLOBAL uint16_t*)(uintptr_t)v.s->cost;    // (global, not FLAT, loads)
             const unsigned ix = (unsigned)(dx - CS_LO), iy = (unsigned)(dy - CS_LO);
             const XA_LDS uint16_t *cs = (const XA_LDS uint16_t*)&v.l->cs[0];
             int a = (v.s->sliced && ix < (unsigned)CS_LEN) ? cs[ix] : tab[dx];
@@ -1539,7 +1558,7 @@ struct Wave
         unsigned i = (unsigned)(mvd - CS_LO);
         if (sliced && i < (unsigned)CS_LEN)
             return uni(((const XA_LDS uint16_t*)&l->cs[0])[i]);
-        return uni(cost[(int16_t)mvd]);
+        return uni(((const XA_GLOBAL uint16_t*)(uintptr_t)cost)[(int16_t)mvd]);
     }
     // mvcost(MV(x,y)) for q-pel x,y: uint16 sum of two table entries (encoder/bitcost.h:46)
     __device__ __forceinline__ int mvcost(int x, int y) const
