@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "x265_amd.hip")
 PART = os.path.join(HERE, "csrc", "x265_amd_part.hip")
-N_PARTS = 3
+N_PARTS = 5
 OUT = os.environ.get("X265AMD_OUT", os.path.join(HERE, "libx265amd.so"))
 DEPS = [SRC, PART] + [os.path.join(HERE, "csrc", f) for f in ("x265_amd_inst.h", "me_device.h", "me_search.h", "me_kernels.h", "me_full.h", "me_hier.h", "me_had.h", "me_lowres.h", "me_field.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "x265_amd.h")]

@@ -1,10 +1,10 @@
-// One group of the heavy kernel instantiations (see x265_amd_inst.h); compiled with -DXA_PART=1, 2, 3.
+// One group of the heavy kernel instantiations (see x265_amd_inst.h); compiled with -DXA_PART=1 .. 5.
 #include "me_kernels.h"
 #include "me_lowres.h"
 #include "me_field.h"
 
 #ifndef XA_PART
-#error "compile with -DXA_PART=1..3"
+#error "compile with -DXA_PART=1..5"
 #endif
 #define XA_INST template
 #include "x265_amd_inst.h"
