@@ -62,7 +62,11 @@ for leg in ("full", "hex"):
                                   "dispatches": max(len(fv), len(wv))}
     out["legs"][leg] = kern
     def total(prefixes, mul):
-        return int(sum((mul * v["fetch_KiB"] + v["write_KiB"]) * 1024 for k, v in kern.items() if k.startswith(prefixes)))
+        # bytes of one step: a kernel launched in fewer steps than the others (the large-PU class has two variants, chosen
+        # by what runs beside it) counts by its share of the steps
+        sel = [v for k, v in kern.items() if k.startswith(prefixes)]
+        steps = max([v["dispatches"] for v in sel] + [1])
+        return int(sum((mul * v["fetch_KiB"] + v["write_KiB"]) * 1024 * v["dispatches"] / steps for v in sel))
     if leg == "full":
         # one step = one k_pack_fenc + one k_full_hier launch (+ the general kernel's launches, listed above)
         out["k_full_hier_bytes_per_launch"] = total(("k_full_hier", "k_pack_fenc"), 1)
