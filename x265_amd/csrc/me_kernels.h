@@ -45,10 +45,11 @@ __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
 
 // ------------------------------------------------------------------------------------------
 // General search: any method / sub-pel level / pixel type.  Jobs come in three classes by PU area:
-// up to 256 pixels on one wavefront, up to 1024 on four (one pass over the PU each), larger on
-// eight (two passes for 64x64; three such workgroups fit a CU, so one job's serial phases -
-// search logic, barriers - overlap another's pixel work).  `idx` (optional) lists the jobs of
-// this launch; without it every job is visited and those of the other classes are skipped.
+// up to 256 pixels and up to 1024 pixels on one wavefront (one and up to four passes over the PU),
+// larger on four or eight (the host picks: four beside launches of the small classes, whose
+// throughput wants the registers and wavefront slots a large PU's waiting workers hold; eight
+// alone).  `idx` (optional) lists the jobs of this launch; without it every job is visited and
+// those of the other classes are skipped.
 constexpr int JOB_CLASSES = 3;
 constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-out)
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
