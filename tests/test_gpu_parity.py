@@ -389,6 +389,31 @@ def test_device_resident_and_planned_paths_agree(eng, oracle):
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10)])
+def test_large_pus_alone_and_beside_small_pus(eng, oracle, bits, depth):
+    """PUs of more than 1024 pixels run on eight wavefronts when their launch has the GPU to itself and on four
+    beside the launches of smaller PUs: both forms, every pattern method, with sub-pel refinement, against the oracle."""
+    W, H = 448, 256
+    fr = synth.make_sequence(W, H, 2, seed=77 + bits, bit_depth=depth if bits == 16 else 8)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    large, small = [], []
+    for m, method in enumerate((J.DIA, J.HEX, J.UMH, J.STAR)):
+        for (w, h) in ((64, 64), (64, 32), (32, 64), (48, 64), (64, 48), (64, 24)):
+            x, y = J.square_pu_grid(W, H, 64)
+            large.append(J.make_jobs(W, H, x, y, w, h, method=method, subme=(5, 2, 7, 3)[m], merange=32, qp=30,
+                                     qmvp=(3 * m - 7, 11 - 5 * m), mvc=np.array([[9, -6], [-14, 4]])))
+        small.append(J.frame_jobs(W, H, sizes=(32, 16, 8), method=method, subme=(5, 2, 7, 3)[m], merange=32, qp=30))
+    for jobs in (np.concatenate(large), np.concatenate(large + small)):
+        exp, _ = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+        jl = eng.make_joblist(jobs, bytes_per_px=bits // 8)
+        got = jl.run(ids[0], [ids[1]])
+        jl.close()
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (len(jobs), len(bad), jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    for i in ids:
+        eng.release_plane(i)
+
+
 class GpuIp:
     """the stand-alone 8-tap filter entry point (x265amd_ipfilter) behind golden_cases.run_ip_suite"""
 
