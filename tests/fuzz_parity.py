@@ -3,7 +3,7 @@
 (oracle/libme_oracle.so, the checker the tests use).  Random frame sizes, contents, bit depths, PU shapes, methods,
 sub-pel levels, predictors, ranges and cost kinds; every batch goes through the host-batch call AND a planned job list.
 
-    python tools/fuzz_parity.py [seconds] [seed]      (default 240 s)
+    python tests/fuzz_parity.py [seconds] [seed]      (default 240 s)
 
 Prints one line per batch and a summary; exits non-zero at the first mismatch."""
 import os, sys, time
