@@ -431,8 +431,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 const uint32_t m = hier_wave_min_last(key32(j8, v8));
                 if (lane == 63)
                 {
-                    uint32_t *sl = s_slot + wv * HIER_SMALL + z;
-                    *sl = m < *sl ? m : *sl;
+                    atomicMin(s_slot + wv * HIER_SMALL + z, m);        // (ds_min_u32: no read-back to wait for)
                 }
             }
 #pragma unroll
@@ -494,8 +493,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                     const uint32_t m = hier_wave_min_last(key32(j16, v16));
                     if (lane == 63)
                     {
-                        uint32_t *sl = s_slot + wv * HIER_SMALL + 64 + q;
-                        *sl = m < *sl ? m : *sl;
+                        atomicMin(s_slot + wv * HIER_SMALL + 64 + q, m);
                     }
                 }
 #pragma unroll

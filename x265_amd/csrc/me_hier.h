@@ -389,8 +389,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, true>(p, C, kx, ky));
                 if (lane == 63)
                 {
-                    uint32_t *sl = s_slot + wv * HIER_SMALL + z;
-                    *sl = m < *sl ? m : *sl;
+                    atomicMin(s_slot + wv * HIER_SMALL + z, m);        // (ds_min_u32: no read-back to wait for)
                 }
             }
 #pragma unroll
@@ -407,8 +406,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                     const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, false>(a16, C, kx, ky));
                     if (lane == 63)
                     {
-                        uint32_t *sl = s_slot + wv * HIER_SMALL + 64 + q;
-                        *sl = m < *sl ? m : *sl;
+                        atomicMin(s_slot + wv * HIER_SMALL + 64 + q, m);
                     }
                 }
 #pragma unroll
