@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Developer aid (not collected by pytest): randomised parity campaign of the two chained whole-frame paths on
+the GPU - the lookahead search over half-resolution plane sets and the predictor-chained field - against the
+CPU oracle.  Random picture sizes (also ones that are no multiple of the CU / PU size), content kinds, pixel
+types, search methods, sub-pel levels, ranges and QPs.
+
+usage: python tests/fuzz_chain.py SECONDS [SEED]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from oracle_ffi import Oracle
+from x265_amd import synth
+from x265_amd.api import Engine
+
+
+def make_frames(rng, w, h, depth, kind):
+    if kind == "motion":
+        return synth.make_sequence(w, h, 2, seed=int(rng.integers(1, 1 << 30)), bit_depth=depth)
+    top = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    out = []
+    for _ in range(2):
+        if kind == "noise":
+            p = rng.integers(0, top + 1, size=(h, w))
+        else:                               # flat with a few steps: many ties
+            p = np.full((h, w), int(rng.integers(0, top + 1)))
+            for _ in range(4):
+                x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+                p[y:, x:] = int(rng.integers(0, top + 1))
+        out.append(synth.pad_plane(p.astype(dt), depth))
+    return out
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    eng, oracle = Engine(0), Oracle()
+    t0 = time.time()
+    n_look = n_field = cus = pus = 0
+    while time.time() - t0 < budget:
+        bits = int(rng.choice([8, 16]))
+        depth = 8 if bits == 8 else 10
+        kind = str(rng.choice(["motion", "motion", "noise", "flat"]))
+        if rng.random() < 0.5:
+            # ---- lookahead: half-resolution sets, 8x8 CUs, neighbour-predicted chain
+            w, h = 2 * int(rng.integers(12, 330)), 2 * int(rng.integers(12, 190))
+            fr = make_frames(rng, w, h, depth, kind)
+            method, subme = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            merange, qp = int(rng.choice([8, 16, 24])), int(rng.integers(8, 40))
+            src = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+            lr = [eng.lowres_create(s) for s in src]
+            got = eng.lookahead_me([lr[1], lr[0]], [lr[0], lr[1]], merange=merange, method=method, subme=subme, qp=qp)
+            cpu = [oracle.lowres_init(f) for f in fr]
+            g = cpu[0][0]
+            for i, (a, b) in enumerate(((1, 0), (0, 1))):
+                exp, _ = oracle.lookahead_me(cpu[a][1], cpu[b][1], g.cu_w, g.cu_h, merange, method, subme, qp, bit_depth=depth)
+                if not np.array_equal(got[i], exp):
+                    bad = np.nonzero(got[i] != exp)[0]
+                    print("MISMATCH lookahead %dx%d bits %d depth %d %s method %d subme %d merange %d qp %d pair %d: CUs %s"
+                          % (w, h, bits, depth, kind, method, subme, merange, qp, i, bad[:5]), flush=True)
+                    sys.exit(1)
+            for p in lr + src:
+                eng.release_plane(p)
+            n_look += 1
+            cus += 2 * g.cu_w * g.cu_h
+            what = "lookahead %4dx%-4d" % (w, h)
+        else:
+            # ---- predictor-chained field of one PU size
+            pw, ph = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)][int(rng.integers(0, 7))]
+            w, h = 8 * int(rng.integers(max(2, pw // 8 * 2), 60)), 8 * int(rng.integers(max(2, ph // 8 * 2), 36))
+            fr = make_frames(rng, w, h, depth, kind)
+            method, subme = int(rng.integers(0, 4)), int(rng.integers(0, 8))
+            merange, qp = int(rng.choice([8, 16, 32, 57])), int(rng.integers(10, 45))
+            ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+            got, got_mvp = eng.field_me(ids[1], ids[0], pw, ph, merange, method, subme, qp)
+            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth)
+            if not (np.array_equal(got, exp) and np.array_equal(got_mvp, exp_mvp)):
+                print("MISMATCH field %dx%d PU %dx%d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
+                      % (w, h, pw, ph, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
+                sys.exit(1)
+            for p in ids:
+                eng.release_plane(p)
+            n_field += 1
+            pus += got.size
+            what = "field %4dx%-4d PU %2dx%-2d" % (w, h, pw, ph)
+        if (n_look + n_field) % 20 == 0:
+            print("case %d ok: %s %2d-bit depth %2d %-6s (%d s)" % (n_look + n_field, what, bits, depth, kind, time.time() - t0), flush=True)
+    print("chained-path campaign: %d lookahead cases (%d CU searches) and %d chained fields (%d PU searches), all bit-exact against "
+          "the oracle (seed %d, %.0f s)" % (n_look, cus, n_field, pus, seed, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()

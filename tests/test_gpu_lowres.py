@@ -152,3 +152,30 @@ def test_lowres_argument_checks(eng):
         eng.lowres_create(small)                # margins below 16
     for p in (lr, src, small):
         eng.release_plane(p)
+
+
+def test_tall_narrow_picture_with_long_vertical_vectors(eng, oracle):
+    """a 32x280 picture of flat areas with steps (found by tests/fuzz_chain.py): its MVs reach 140 half-resolution
+    pixels, so UMH's vertical cross singles - measured at x = omv.x + omv.y (encoder/motion.cpp:176,271-273) - land in
+    the columns that pad the plane's stride, which must read as zero like the oracle's zero-initialised planes"""
+    d = np.load(os.path.join(G.GOLDEN_DIR, "lookahead_tall_narrow_u8.npz"), allow_pickle=False)
+    fr = [d["f0"], d["f1"]]
+    src = [eng.upload_plane(f) for f in fr]
+    lr = [eng.lowres_create(s) for s in src]
+    cpu = [oracle.lowres_init(f) for f in fr]
+    g = cpu[0][0]
+    for k in range(2):
+        for which in range(4):
+            got = eng.download_plane(lr[k], g.padded_shape, np.uint8, which=which)
+            assert np.array_equal(got, cpu[k][1][which]), (k, which)       # stride padding included
+    longest = 0
+    for method in range(4):
+        for merange in (8, 24):
+            got = eng.lookahead_me([lr[0], lr[1]], [lr[1], lr[0]], merange=merange, method=method, subme=1, qp=21)
+            for i, (a, b) in enumerate(((0, 1), (1, 0))):
+                exp, _ = oracle.lookahead_me(cpu[a][1], cpu[b][1], g.cu_w, g.cu_h, merange, method, 1, 21)
+                assert np.array_equal(got[i], exp), (method, merange, i, np.nonzero(got[i] != exp)[0][:5])
+                longest = max(longest, int(np.abs(exp["mvy"].astype(np.int32)).max()))
+    assert longest > 4 * 64             # the long vectors are really there
+    for p in lr + src:
+        eng.release_plane(p)

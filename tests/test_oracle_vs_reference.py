@@ -63,3 +63,21 @@ def test_vector_primitive_build_equals_c_build(oracle):
     b = ref.search(fr[0], [fr[1]], jobs)
     bad = np.nonzero(a != b)[0]
     assert bad.size == 0, (jobs[bad[:2]], a[bad[:2]], b[bad[:2]])
+
+
+def test_tall_narrow_lookahead_case(oracle):
+    """the picture of tests/golden/lookahead_tall_narrow_u8.npz (long vertical vectors; UMH's cross singles read the
+    stride padding of the half-resolution planes): restatement and compiled reference agree on zero-initialised planes"""
+    import os
+    import golden_cases as G
+    d = np.load(os.path.join(G.GOLDEN_DIR, "lookahead_tall_narrow_u8.npz"), allow_pickle=False)
+    fr = [d["f0"], d["f1"]]
+    ref = Reference(8)
+    cpu = [oracle.lowres_init(f) for f in fr]
+    rcp = [ref.lowres_init(f) for f in fr]
+    g = cpu[0][0]
+    for method in range(4):
+        exp, _ = oracle.lookahead_me(cpu[0][1], cpu[1][1], g.cu_w, g.cu_h, 24, method, 1, 21)
+        got = ref.lookahead_me(rcp[0][1], rcp[1][1], g.cu_w, g.cu_h, 24, method, 1, 21)
+        got = got[0] if isinstance(got, tuple) else got
+        assert np.array_equal(exp, got), method

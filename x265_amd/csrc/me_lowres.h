@@ -16,7 +16,8 @@ namespace xa {
 // ------------------------------------------------------------------------------------------
 // Half-resolution planes.  One thread produces 4 adjacent pixels of all four planes (F, H, V, C)
 // at one position of the PADDED output domain: positions in the margins take the value of the
-// nearest picture pixel, which is what extending the borders afterwards yields.  The source is a
+// nearest picture pixel, which is what extending the borders afterwards yields; the columns that pad
+// the stride behind the right margin are zero.  The source is a
 // border-replicated plane; its reads reach at most 2 pixels beyond twice the rounded-up
 // half-resolution size (<= 16 pixels into its margins).
 template <typename PIX>
@@ -53,6 +54,12 @@ __global__ void __launch_bounds__(256) k_lowres_init(const PIX *src, int64_t slo
         o[1][i] = avg4(a[0][1], a[1][1], a[0][2], a[1][2]);
         o[2][i] = avg4(a[1][0], a[2][0], a[1][1], a[2][1]);
         o[3][i] = avg4(a[1][1], a[2][1], a[1][2], a[2][2]);
+        // Columns behind the right margin only pad the stride to a multiple of 32.  The reference leaves them
+        // uninitialised (common/lowres.cpp:37-51), yet UMH's vertical cross singles, measured at x = omv.x + omv.y
+        // (encoder/motion.cpp:176,271-273), can land in them when the vertical MV is large.  They hold zeros here,
+        // as in a zero-initialised allocation, so that such searches are deterministic.
+        if (x0 + i >= width + 2 * mx)
+            o[0][i] = o[1][i] = o[2][i] = o[3][i] = 0;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++)
