@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer aid (not collected by pytest): randomised parity campaign of the entry points the other two campaigns
 (fuzz_parity.py, fuzz_chain.py) do not reach - independent search jobs against half-resolution plane sets through
-the batch call, bidirectional-refinement jobs (X265AMD_BIPRED), and batched costs of motion-compensated blocks -
+the batch call, bidirectional-refinement jobs (X265AMD_BIPRED), batched costs of motion-compensated blocks, and the
+two entry points that take job arrays resident in device memory (the allocating one and the allocation-free one) -
 against the CPU oracle.
 
 usage: python tests/fuzz_misc.py SECONDS [SEED]"""
@@ -35,14 +36,14 @@ def main():
     rng = np.random.default_rng(seed)
     eng, oracle = Engine(0), Oracle()
     t0 = time.time()
-    count = {"lowres": 0, "bipred": 0, "mc": 0}
-    work = {"lowres": 0, "bipred": 0, "mc": 0}
+    count = {"lowres": 0, "bipred": 0, "mc": 0, "device": 0}
+    work = {"lowres": 0, "bipred": 0, "mc": 0, "device": 0}
     cases = 0
     while time.time() - t0 < budget:
         bits = int(rng.choice([8, 16]))
         depth = 8 if bits == 8 else 10
         kind = str(rng.choice(["motion", "motion", "noise", "flat"]))
-        mode = str(rng.choice(["lowres", "bipred", "mc"]))
+        mode = str(rng.choice(["lowres", "bipred", "mc", "device"]))
         if mode == "lowres":
             w, h = 2 * int(rng.integers(40, 260)), 2 * int(rng.integers(40, 150))
             fr = make_frames(rng, w, h, depth, kind)
@@ -108,6 +109,43 @@ def main():
                 work[mode] += len(jobs)
             for p in ids:
                 eng.release_plane(p)
+        elif mode == "device":
+            import torch
+            w, h = 8 * int(rng.integers(10, 60)), 8 * int(rng.integers(10, 36))
+            fr = make_frames(rng, w, h, depth, kind)
+            ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+            parts = []
+            for _ in range(int(rng.integers(4, 60))):
+                pw, ph = SHAPES[int(rng.integers(0, len(SHAPES)))]
+                method = int(rng.integers(0, 5))
+                if pw > w or ph > h or (method == J.UMH and pw == 4 and ph == 4):
+                    continue
+                px = int(rng.integers(0, (w - pw) // 4 + 1)) * 4
+                py = int(rng.integers(0, (h - ph) // 4 + 1)) * 4
+                k = int(rng.integers(0, 5))
+                parts.append(J.make_jobs(w, h, [px], [py], pw, ph, method=method, subme=int(rng.integers(0, 8)),
+                                         merange=int(rng.integers(1, 24)) if method == J.FULL else int(rng.integers(1, 64)),
+                                         qp=int(rng.integers(8, 45)), qmvp=(int(rng.integers(-100, 100)), int(rng.integers(-100, 100))),
+                                         mvc=rng.integers(-200, 200, (k, 2)) if k else None, icost=int(rng.choice([0, 0, 0, 1, 2])),
+                                         ref_idx=int(rng.integers(0, 2))))
+            if parts:
+                jobs = np.concatenate(parts)
+                exp, _ = oracle.search(fr[0], [fr[1], fr[0]], jobs, bit_depth=depth)
+                dev = torch.device("cuda", 0)
+                dj = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+                for which in ("allocating", "allocation-free"):
+                    do = torch.zeros(len(jobs) * 8, dtype=torch.uint8, device=dev)
+                    if which == "allocating":
+                        eng.search_device(ids[0], [ids[1], ids[0]], dj.data_ptr(), len(jobs), do.data_ptr())
+                    else:
+                        eng.search_device_noalloc(ids[0], [ids[1], ids[0]], dj.data_ptr(), len(jobs), do.data_ptr())
+                    eng.sync()
+                    got = do.cpu().numpy().view(J.RESULT_DTYPE)
+                    if not np.array_equal(got, exp):
+                        fail("device-resident jobs %dx%d %d-bit %s (%s entry point)" % (w, h, bits, kind, which), jobs, got, exp)
+                work[mode] += len(jobs)
+            for p in ids:
+                eng.release_plane(p)
         else:
             w, h = 8 * int(rng.integers(10, 50)), 8 * int(rng.integers(10, 30))
             fr = make_frames(rng, w, h, depth, kind)
@@ -138,8 +176,10 @@ def main():
         if cases % 50 == 0:
             print("case %d ok (%s, %d-bit, %s; %d s)" % (cases, mode, bits, kind, time.time() - t0), flush=True)
     print("campaign: %d half-resolution batches (%d jobs), %d bidirectional batches (%d jobs, each through both entry paths), "
-          "%d motion-compensated cost cases (%d costs), all bit-exact against the oracle (seed %d, %.0f s)"
-          % (count["lowres"], work["lowres"], count["bipred"], work["bipred"], count["mc"], work["mc"], seed, time.time() - t0), flush=True)
+          "%d motion-compensated cost cases (%d costs), %d device-resident batches (%d jobs, each through the allocating and the "
+          "allocation-free entry point), all bit-exact against the oracle (seed %d, %.0f s)"
+          % (count["lowres"], work["lowres"], count["bipred"], work["bipred"], count["mc"], work["mc"], count["device"], work["device"],
+             seed, time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":
