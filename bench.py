@@ -172,7 +172,7 @@ def main():
     trace("job lists planned")
     from x265_amd import dist as xd
 
-    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=not os.environ.get("X265AMD_NO_OVERLAP"))
+    ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=bool(os.environ.get("X265AMD_OVERLAP")))
     if os.environ.get("X265AMD_BENCH_TRACE"):       # a watchdog: what is busy when a rank stops making progress
         import threading
 

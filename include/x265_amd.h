@@ -215,9 +215,13 @@ typedef struct x265amd_me_result
 
 /* jobs / out in host memory; blocks until the results are in `out`.  X265AMD_ERR_RANGE if a job's
  * bounds (+3 pixels of pattern overshoot, +3/+4 of filter apron) leave the reference plane's margins.
- * Job lists are checked the same way when they run (once per plane geometry); only the device-array
- * form cannot check (its jobs are not visible to the host; the kernels clamp addresses, so a violation
- * measures other pixels than the reference would, it does not fault). */
+ * Job lists are checked the same way when they run (once per plane geometry).  The device-array forms
+ * cannot check on the host (their jobs are not visible to it): there the kernels check every job's
+ * FIELDS (sizes, method, subme, qp, numc, ref_idx, icost, merange; the same predicate as the host
+ * entry points) and give a job that fails the result (MV 0, cost X265AMD_ERR_INVALID) without
+ * searching it; the WINDOW of a job is not checked against the plane margins, pixel addresses are
+ * clamped into the plane allocation instead, so such a job measures other pixels than the reference
+ * would, it does not fault. */
 int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                             const x265amd_me_job *jobs, int n, x265amd_me_result *out);
 
@@ -231,8 +235,9 @@ int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *r
  * Identical results to x265amd_me_search_batch_device; the per-job scratch of the exhaustive kernel
  * (partial winners, work items) lives in a fixed device array inside the library instead of buffers
  * grown on demand, so: n <= 65536 jobs per call (X265AMD_ERR_INVALID beyond; split the batch); the call
- * performs no hipMalloc / hipFree; all contexts on one GPU share that GPU's array, so calls that overlap
- * in time on one GPU (two contexts, two threads) race - serialise them. */
+ * performs no hipMalloc / hipFree; all contexts on one GPU share that GPU's array: the library orders
+ * every such call behind the previous one on that GPU with a stream event (created at x265amd_create),
+ * so calls from several contexts or threads are serialised on the GPU rather than racing. */
 int x265amd_me_search_batch_device_noalloc(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                                            const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
 
@@ -272,11 +277,15 @@ int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
 int x265amd_lookahead_me(x265amd_ctx *ctx, int n_pairs, const int *enc_lowres, const int *ref_lowres,
                          int merange, int method, int subme, int qp, x265amd_me_result *out);
 /* The device array holding the last call's fields.  The pointer stays valid until the next
- * x265amd_lookahead_me call on the context (which may re-allocate it) or x265amd_destroy. */
+ * x265amd_lookahead_me call on the context (which may re-allocate it) or x265amd_destroy: consume
+ * (or copy) an asynchronous call's results before the next call of the same kind. */
 const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *ctx);
-/* Waits for the lookahead searches queued so far and reports whether the last call completed: 0, or
- * X265AMD_ERR_HIP if a CU row gave up waiting for the row below it (its field is then not valid).
- * The synchronous form of x265amd_lookahead_me (out != NULL) performs this check itself. */
+/* Waits for the lookahead and field searches queued so far and reports whether every asynchronous call
+ * since the last x265amd_lookahead_status completed: 0, or X265AMD_ERR_HIP if a row of a lookahead
+ * search gave up waiting for the row below it, or a row of a field search for the row above it (that
+ * call's field is then not valid; x265amd_last_error says which kind).  Failures of the two kinds are
+ * kept in separate words that only this call clears, so a later call does not hide an earlier failure.
+ * The synchronous forms (out != NULL) perform this check themselves. */
 int x265amd_lookahead_status(x265amd_ctx *ctx);
 
 /* ---- whole-frame motion field with the encoder's predictor chain -------------------------------

@@ -138,15 +138,11 @@ def test_4k_lookahead_batch_through_plane_ring(oracle):
     encs = [torch.from_numpy(f).to(dev) for f in fr[2:]]
     enc_ids = [eng.wrap_device_plane(t.data_ptr(), W4K, H4K, stride, 1, 8) for t in encs]
     ring = xd.PlaneRing(bufs, engine=eng, src=0, overlap=True)
-    cur = torch.cuda.current_stream(dev)
 
     def publish(k):
         # the owner writes reference k (the frames alternate between the two references) into the ring
         # buffer it is about to broadcast, once the searches still reading that buffer are done
-        b = ring.slot(k)
-        if ring.free[b] is not None:
-            cur.wait_event(ring.free[b])
-        bufs[b].copy_(host_refs[k & 1], non_blocking=True)
+        ring.publish(k, host_refs[k & 1])
 
     publish(0)
     for k in range(NF):                     # nothing in this loop waits on the host

@@ -62,3 +62,41 @@ def test_noalloc_entry_point_equals_the_allocating_one(oracle):
     for i in ids:
         eng.release_plane(i)
     eng.close()
+
+
+def test_device_array_entry_points_refuse_bad_job_fields(oracle):
+    """Jobs that live only in device memory cannot be checked on the host: the kernels apply the host entry
+    points' field checks per job, give a failing job (MV 0, cost X265AMD_ERR_INVALID) without touching a plane
+    or cost table through its fields, and search the jobs around it as usual - through both device-array
+    entry points; a second context using the same GPU's scratch array right behind the first gets the same
+    results (the library serialises the two calls on the GPU)."""
+    import torch
+    from x265_amd.api import Engine
+    dev = torch.device("cuda", 0)
+    eng, eng2 = Engine(0), Engine(0)
+    W, H = 416, 240
+    fr = synth.make_sequence(W, H, 2, seed=78)
+    ids = [eng.upload_plane(f) for f in fr]
+    ids2 = [eng2.upload_plane(f) for f in fr]
+    rng = np.random.default_rng(6)
+    jobs = _jobs(W, H, rng, 6)
+    bad = {3: ("qp", 200), 10: ("ref_idx", 7), 17: ("numc", 9), 25: ("method", 77), 31: ("w", 5), 40: ("subme", 8), 44: ("icost", 3)}
+    broken = jobs.copy()
+    for i, (field, value) in bad.items():
+        broken[i][field] = value
+    good = np.array([i for i in range(len(jobs)) if i not in bad])
+    exp, _ = oracle.search(fr[0], [fr[1]], np.ascontiguousarray(jobs[good]), threads=4)
+    dj = torch.from_numpy(np.frombuffer(broken.tobytes(), dtype=np.uint8).copy()).to(dev)
+    outs = []
+    for e, p, entry in ((eng, ids, "search_device"), (eng, ids, "search_device_noalloc"), (eng2, ids2, "search_device_noalloc")):
+        do = torch.zeros(len(jobs) * 8, dtype=torch.uint8, device=dev)
+        getattr(e, entry)(p[0], [p[1]], dj.data_ptr(), len(jobs), do.data_ptr())
+        outs.append((e, do))
+    for e, do in outs:
+        e.sync()
+        got = do.cpu().numpy().view(J.RESULT_DTYPE)
+        assert np.array_equal(got[good], exp), np.nonzero(got[good] != exp)[0][:5]
+        for i in bad:
+            assert (int(got[i]["mvx"]), int(got[i]["mvy"]), int(got[i]["cost"])) == (0, 0, -2), (i, got[i])
+    eng.close()
+    eng2.close()

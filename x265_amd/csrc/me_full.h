@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(FULL_THREADS) k_full_items(BatchParams P, cons
                                                              const int *item_jobs, const FullItem *items, int n_items,
                                                              FullBest *fb, int fb_stride, int lds_dwords)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __align__(16) uint32_t lds[];
     int id = blockIdx.x;
     if (id >= n_items)
         return;
@@ -605,7 +605,7 @@ __global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, i
     FullItem it;
     it.first = id;
     item_jobs[id] = id;
-    it.count = full_kernel_eligible(j, P.planes[P.enc_plane].bpp) ? 1 : 0;
+    it.count = job_fields_valid(j, P.n_refs) && full_kernel_eligible(j, P.planes[P.enc_plane].bpp) ? 1 : 0;
     const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1), W4 = j.w >> 2;
     const int ND = (XGe + W4) * P.planes[P.enc_plane].bpp;      // dwords per window row

@@ -261,8 +261,9 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     const int x_lo = NC * (it.t_lo - y_lo * XP);        // slab-local candidate index = (y - y_lo) * nxw + x - x_lo
 
     // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
+    // (the window area is rounded up to an even dword count, so the 64-bit slots behind it are 8-byte aligned)
     uint32_t *s_win = lds;
-    uint16_t *s_cx = (uint16_t*)(s_win + it.win_rows * pitch);
+    uint16_t *s_cx = (uint16_t*)(s_win + ((it.win_rows * pitch + 1) & ~1));
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
@@ -379,7 +380,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 {
                     const unsigned long long m = wave_min_u64(key64(jid, v));
                     if (lane == 0)
-                        *sl = m < *sl ? m : *sl;
+                        atomicMin(sl, m);                              // (ds_min_u64)
                 }
                 else
                 {
@@ -388,7 +389,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                     {
                         const unsigned long long m64 = ((unsigned long long)(m >> HAD_RIDX_BITS) << 32) |
                                                        (uint32_t)(y_lo * nxw + x_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1)));
-                        *sl = m64 < *sl ? m64 : *sl;
+                        atomicMin(sl, m64);
                     }
                 }
             }
@@ -510,10 +511,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                     {
                         const unsigned long long m = wave_min_u64(key64(j32, a32));
                         if (lane == 0)
-                        {
-                            unsigned long long *sl = s_big + wv * 5 + q32;
-                            *sl = m < *sl ? m : *sl;
-                        }
+                            atomicMin(s_big + wv * 5 + q32, m);
                     }
 #pragma unroll
                     for (int c = 0; c < NC; c++)
@@ -551,10 +549,7 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         {
             const unsigned long long m = wave_min_u64(key64(j64, a64));
             if (lane == 0)
-            {
-                unsigned long long *sl = s_big + wv * 5 + 4;
-                *sl = m < *sl ? m : *sl;
-            }
+                atomicMin(s_big + wv * 5 + 4, m);
         }
     }
     __syncthreads();
@@ -622,7 +617,7 @@ __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, con
                                                               const HierItem *items, int n_items, const uint32_t *packed,
                                                               FullBest *fb, int fb_stride)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __align__(16) uint32_t lds[];
     const int id = blockIdx.x;
     if (id >= n_items)
         return;

@@ -255,8 +255,9 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
     const int yq_lo = it.t_lo / XG;                 // first row quad of this slab = first staged candidate row / R
 
     // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
+    // (the window area is rounded up to an even dword count, so the 64-bit slots behind it are 8-byte aligned)
     uint32_t *s_win = lds;
-    uint16_t *s_cx = (uint16_t*)(s_win + it.win_rows * pitch);
+    uint16_t *s_cx = (uint16_t*)(s_win + ((it.win_rows * pitch + 1) & ~1));
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HIER_WAVES * HIER_SMALL);
@@ -428,10 +429,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                                                                      J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
                         m = wave_min_u64(m);
                         if (lane == 0)
-                        {
-                            unsigned long long *sl = s_big + wv * 5 + q32;
-                            *sl = m < *sl ? m : *sl;
-                        }
+                            atomicMin(s_big + wv * 5 + q32, m);         // (ds_min_u64)
                     }
 #pragma unroll
                     for (int i = 0; i < R; i++)
@@ -456,10 +454,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                                                          J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
             m = wave_min_u64(m);
             if (lane == 0)
-            {
-                unsigned long long *sl = s_big + wv * 5 + 4;
-                *sl = m < *sl ? m : *sl;
-            }
+                atomicMin(s_big + wv * 5 + 4, m);
         }
     }
     __syncthreads();
@@ -512,7 +507,7 @@ __global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const
                                                             const HierItem *items, int n_items, const uint32_t *packed,
                                                             FullBest *fb, int fb_stride)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __align__(16) uint32_t lds[];
     const int id = blockIdx.x;
     if (id >= n_items)
         return;

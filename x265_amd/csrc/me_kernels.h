@@ -21,6 +21,25 @@ struct BatchParams
                                           // (without it: exactly the jobs full_kernel_eligible accepts)
 };
 
+// The field checks every entry path applies to a job: the host entry points refuse a batch that fails them
+// (X265AMD_ERR_INVALID); the device-array entry points, whose jobs the host cannot see, apply them per job
+// on the device: a failing job gets the result (MV 0, cost X265AMD_ERR_INVALID) and is never searched.
+__device__ __host__ inline bool job_dim_valid(int v) { return v == 4 || v == 8 || v == 12 || v == 16 || v == 24 || v == 32 || v == 48 || v == 64; }
+template <class J>
+__device__ __host__ inline bool job_fields_valid(const J &j, int n_refs)
+{
+    if (!job_dim_valid(j.w) || !job_dim_valid(j.h))
+        return false;
+    if (j.method > X265AMD_BIPRED || j.subme > 7 || j.qp > 51 || j.numc > X265AMD_MAX_MVC ||
+        j.ref_idx >= n_refs || j.icost > X265AMD_SA8D || j.merange < 0)
+        return false;
+    if (j.method == X265AMD_UMH && j.w == 4 && j.h == 4)      // (the reference asserts, encoder/motion.cpp:447)
+        return false;
+    if (j.method == X265AMD_BIPRED && (j.icost != X265AMD_SAD || j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y))
+        return false;
+    return true;
+}
+
 // Does the dedicated exhaustive kernel handle this job?  (SAD metric, bounded range)
 template <class J>
 __device__ __host__ inline bool full_kernel_eligible(const J &j, int bpp)
@@ -65,6 +84,16 @@ __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::N
     const int id = idx ? idx[blockIdx.x] : (int)blockIdx.x;
     JobRegs j;
     j.load(jobs + id);
+    if (!idx && !job_fields_valid(j, P.n_refs))
+    {
+        // (only the device-array entry points come without an index list; planned lists were checked on the host)
+        if (cls == 0 && threadIdx.x == 0)
+        {
+            out[id].mvx = out[id].mvy = 0;
+            out[id].cost = X265AMD_ERR_INVALID;
+        }
+        return;
+    }
     if (job_class(j.w, j.h) != cls)
         return;
     const PlaneDesc &enc = P.planes[P.enc_plane];

@@ -1059,6 +1059,10 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 void *g_scratch_ptr[MAX_DEVICES];       // device address of `scratch` on device i (NULL: not looked up yet)
+// One event per device, recorded behind every call that uses the device's scratch array; the next such call (from any
+// context) makes its stream wait for it first, so calls that overlap in time are serialised on the GPU.  Created with
+// the address look-up, so the entry point itself creates nothing.
+hipEvent_t g_scratch_ev[MAX_DEVICES];
 
 // with `device` current
 hipError_t resolve_scratch(int device)
@@ -1074,6 +1078,9 @@ hipError_t resolve_scratch(int device)
         return e;
     if (!p)
         return hipErrorInvalidSymbol;
+    e = hipEventCreateWithFlags(&g_scratch_ev[device], hipEventDisableTiming);
+    if (e != hipSuccess)
+        return e;
     g_scratch_ptr[device] = p;
     return hipSuccess;
 }
@@ -1397,6 +1404,18 @@ int x265amd_plane_release(x265amd_ctx *c, int id)
 
 namespace {
 
+// The chained kernels report a row that gave up waiting by OR-ing into an error word: one word for the lookahead
+// searches, one for the predictor-chained fields, zeroed when first allocated and then only when they are read out.
+constexpr int ERR_WORD_LOOKAHEAD = 0, ERR_WORD_FIELD = 1;
+int ensure_error_words(x265amd_ctx *c)
+{
+    if (c->look_progress.p)
+        return 0;
+    if (int rc = ensure(c, c->look_progress, 2 * sizeof(int))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, 2 * sizeof(int), c->stream));
+    return 0;
+}
+
 // geometry of Lowres::create (common/lowres.cpp:30-58) for a source plane
 struct LowresGeom { int width, lines, stride, cu_w, cu_h; int64_t elems; };
 
@@ -1563,15 +1582,14 @@ int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, con
     if (int rc = sync_planes(c)) return rc;
     if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
     if (int rc = ensure(c, c->look_results, n_res * sizeof(x265amd_me_result))) return rc;
-    if (int rc = ensure(c, c->look_progress, sizeof(int))) return rc;
+    if (int rc = ensure_error_words(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));          // hp goes out of scope
-    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->look_results.p, LOOK_UNSET, n_res * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    int *error = (int*)c->look_progress.p;
+    int *error = (int*)c->look_progress.p + ERR_WORD_LOOKAHEAD;
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
     const dim3 grid(n_pairs * cu_h), block(64);
     if (first->bpp == 1)
@@ -1595,7 +1613,10 @@ int x265amd_lookahead_me(x265amd_ctx *c, int n_pairs, const int *enc_lowres, con
     HIPCHK(c, hipMemcpyAsync(&h_err, error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_err)
+    {
+        HIPCHK(c, hipMemsetAsync(error, 0, sizeof(int), c->stream));
         return fail(c, X265AMD_ERR_HIP, "lookahead search: a CU row waited too long for the row below it");
+    }
     return 0;
 }
 
@@ -1655,11 +1676,10 @@ int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     if (int rc = sync_planes(c)) return rc;
     if (int rc = ensure(c, c->field_results, n * sizeof(x265amd_me_result))) return rc;
     if (int rc = ensure(c, c->field_mvp, n * sizeof(int))) return rc;
-    if (int rc = ensure(c, c->look_progress, sizeof(int))) return rc;
+    if (int rc = ensure_error_words(c)) return rc;
     if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));      // hp dies here
-    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->field_results.p, LOOK_UNSET, n * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
     if (c->timing)
@@ -1668,10 +1688,10 @@ int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     const int cls = job_class(pu_w, pu_h);
     if (e.bpp == 1)
         launch_field<uint8_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
-                              (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
+                              (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p + ERR_WORD_FIELD);
     else
         launch_field<uint16_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
-                               (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p);
+                               (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p + ERR_WORD_FIELD);
     HIPCHK(c, hipGetLastError());
     if (c->timing)
     {
@@ -1684,10 +1704,13 @@ int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     HIPCHK(c, hipMemcpyAsync(out, c->field_results.p, n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
     if (out_mvp)
         HIPCHK(c, hipMemcpyAsync(out_mvp, c->field_mvp.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&h_err, c->look_progress.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&h_err, (int*)c->look_progress.p + ERR_WORD_FIELD, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_err)
+    {
+        HIPCHK(c, hipMemsetAsync((int*)c->look_progress.p + ERR_WORD_FIELD, 0, sizeof(int), c->stream));
         return fail(c, X265AMD_ERR_HIP, "field search: a PU row waited too long for the row above it");
+    }
     return 0;
 }
 
@@ -1710,11 +1733,18 @@ int x265amd_lookahead_status(x265amd_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->look_progress.p)
         return 0;                       // no lookahead search was ever queued
-    int h_err = 0;
-    HIPCHK(c, hipMemcpyAsync(&h_err, c->look_progress.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // the kernels OR their failures into one word per kind; they are cleared only here (and by a synchronous call that
+    // reports them itself), so an asynchronous call's failure survives later calls until it is asked for
+    int h_err[2] = { 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(h_err, c->look_progress.p, sizeof(h_err), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->look_progress.p, 0, sizeof(h_err), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h_err)
+    if (h_err[ERR_WORD_LOOKAHEAD] && h_err[ERR_WORD_FIELD])
+        return fail(c, X265AMD_ERR_HIP, "lookahead search: a CU row waited too long for the row below it; field search: a PU row waited too long for the row above it");
+    if (h_err[ERR_WORD_LOOKAHEAD])
         return fail(c, X265AMD_ERR_HIP, "lookahead search: a CU row waited too long for the row below it");
+    if (h_err[ERR_WORD_FIELD])
+        return fail(c, X265AMD_ERR_HIP, "field search: a PU row waited too long for the row above it");
     return 0;
 }
 
@@ -1851,13 +1881,12 @@ static int validate_jobs(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int 
         const x265amd_me_job &j = jobs[i];
         if (!valid_dim(j.w) || !valid_dim(j.h))
             return fail(c, X265AMD_ERR_INVALID, "job size is not a partition size");
-        if (j.method > X265AMD_BIPRED || j.subme > 7 || j.qp > 51 || j.numc > X265AMD_MAX_MVC ||
-            j.ref_idx >= n_refs || j.icost > X265AMD_SA8D || j.merange < 0)
-            return fail(c, X265AMD_ERR_INVALID, "job field out of range");
         if (j.method == X265AMD_UMH && j.w == 4 && j.h == 4)
             return fail(c, X265AMD_ERR_INVALID, "UMH does not support 4x4 (the reference asserts, encoder/motion.cpp:447)");
         if (j.method == X265AMD_BIPRED && (j.icost != X265AMD_SAD || j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y))
             return fail(c, X265AMD_ERR_INVALID, "a bidirectional-refinement job needs a non-empty range and the SAD metric");
+        if (!job_fields_valid(j, n_refs))       // (the same predicate the device-array entry points apply per job)
+            return fail(c, X265AMD_ERR_INVALID, "job field out of range");
         if (j.method == X265AMD_FULL || j.method == X265AMD_BIPRED)
             *any_full = true;
     }
@@ -1960,13 +1989,18 @@ int x265amd_me_search_batch_device_noalloc(x265amd_ctx *c, int enc_plane, const 
     }
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = sync_planes(c)) return rc;          // (a copy from pinned memory; nothing is allocated)
+    // every context on this GPU shares the array: order this call behind the last one that used it
+    std::lock_guard<std::mutex> gs(g_scratch_mu);
     unsigned char *sp = (unsigned char*)g_scratch_ptr[c->device];
     if (!sp)
         return fail(c, X265AMD_ERR_HIP, "the scratch array's device address is unknown");
+    HIPCHK(c, hipStreamWaitEvent(c->stream, g_scratch_ev[c->device], 0));
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
-    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
-                                   (FullBest*)(sp + NOALLOC_FB_OFF), (FullItem*)(sp + NOALLOC_ITEMS_OFF),
-                                   (int*)(sp + NOALLOC_IJOBS_OFF));
+    const int rc = launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
+                                           (FullBest*)(sp + NOALLOC_FB_OFF), (FullItem*)(sp + NOALLOC_ITEMS_OFF),
+                                           (int*)(sp + NOALLOC_IJOBS_OFF));
+    HIPCHK(c, hipEventRecord(g_scratch_ev[c->device], c->stream));
+    return rc;
 }
 
 int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, int bytes_per_px,

@@ -78,12 +78,17 @@ class PlaneRing:
     only hands out buffer indices; with a process group of one rank the collective still runs (it moves
     nothing), which is how a single GPU exercises this path.
 
-    overlap=False keeps the broadcast of frame k + 1 out of prefetch(): it then starts in acquire(k + 1),
-    behind search k on the engine's stream (serial, still without host waits).
+    The OWNER of the planes (rank `src`) refills a buffer with plane k before its broadcast.  That write must
+    not start while searches of frame k - 2 still read the buffer: call publish(k, tensor) (or wait_free(k) and
+    write the buffer yourself, on torch's current stream) - never write buffers[slot(k)] directly.
+
+    overlap=False (the default) keeps the broadcast of frame k + 1 out of prefetch(): it is then queued in
+    acquire(k + 1) (serial, still without host waits).  overlap=True queues it beside search k; that mode has
+    run on one GPU with a one-rank group only, so it is opt-in.
 
     On the CPU (gloo tests) the collective is synchronous and there is nothing to order."""
 
-    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = True):
+    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = False):
         assert len(buffers) == 2
         self.buffers = list(buffers)
         self.engine = engine
@@ -101,6 +106,24 @@ class PlaneRing:
 
     def slot(self, k: int) -> int:
         return k & 1
+
+    def wait_free(self, k: int, stream=None) -> None:
+        """Order `stream` (default: torch's current stream) behind the searches that last read the buffer
+        plane k goes into (frame k - 2's).  The owner calls this before it writes plane k into that buffer."""
+        b = self.slot(k)
+        if self.gpu and self.free[b] is not None:
+            st = stream if stream is not None else torch.cuda.current_stream(self.buffers[b].device)
+            st.wait_event(self.free[b])
+
+    def publish(self, k: int, plane: torch.Tensor) -> int:
+        """Owner side: copy plane k (a host or device tensor of the buffers' shape) into its ring buffer once
+        the searches still reading that buffer are done, on torch's current stream (the stream the broadcast is
+        queued on, so the broadcast follows the copy).  Ranks other than `src` do nothing.  Returns the slot."""
+        b = self.slot(k)
+        if rank() == self.src:
+            self.wait_free(k)
+            self.buffers[b].copy_(plane, non_blocking=True)
+        return b
 
     def _broadcast(self, k: int) -> None:
         b = self.slot(k)
