@@ -476,23 +476,32 @@ def main():
             parts.append(J.make_jobs(W4, H4, cx4.ravel() + ox, cy4.ravel() + oy, w, h, method=J.FULL, subme=0, merange=16, qp=27,
                                      icost=J.SA8D))
     all_jobs = np.concatenate(parts)
-    jl_all = eng.make_joblist(all_jobs, bytes_per_px=2)
-    for _ in range(2):
-        jl_all.run(ids4[1], [ids4[0]], fetch=False)
-    eng.sync()
-    eng.eval_count(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        jl_all.run(ids4[1], [ids4[0]], fetch=False)
-    eng.sync()
-    all_dt = (time.perf_counter() - t0) / 5
-    all_evals = eng.eval_count() / 5
-    k_all_ms, k_all_tail_ms = eng.kernel_times()
-    all_res = jl_all.results()
-    jl_all.close()
-    line["sa8d_full_4k10"]["all_partitions"] = {"jobs_per_frame": int(len(all_jobs)), "evals_per_frame": all_evals,
-                                                "value": all_evals / all_dt, "unit": "evals/s", "ms_per_frame": all_dt * 1e3,
-                                                "kernel_ms": k_all_ms, "search_kernel_ms": k_all_tail_ms}
+
+    def run_4k10(jobs, steps):
+        jl = eng.make_joblist(jobs, bytes_per_px=2)
+        for _ in range(2):
+            jl.run(ids4[1], [ids4[0]], fetch=False)
+        eng.sync()
+        eng.eval_count(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            jl.run(ids4[1], [ids4[0]], fetch=False)
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        ev = eng.eval_count() / steps
+        k_ms, tail_ms = eng.kernel_times()
+        res = jl.results()
+        jl.close()
+        return res, {"jobs_per_frame": int(len(jobs)), "evals_per_frame": ev, "value": ev / dt, "unit": "evals/s",
+                     "ms_per_frame": dt * 1e3, "kernel_ms": k_ms, "search_kernel_ms": tail_ms}
+
+    all_res, line["sa8d_full_4k10"]["all_partitions"] = run_4k10(all_jobs, 5)
+    line["sa8d_full_4k10"]["all_partitions"]["workload"] = "the 209 partitions of every CTU that are made of 8x8 cells (85 squares + 124 rectangles)"
+    # BASELINE configs[4]'s full shape list: all 593 PUs of every CTU, 24 shapes from 64x64 down to 8x4 / 4x8 (those with
+    # 4- or 12-pixel sides are priced by sa8d_inter's SATD recipe, from the 4x4 quadrant sums of the same pass)
+    shape_jobs = J.all_partition_jobs(W4, H4, method=J.FULL, subme=0, merange=16, qp=27, icost=J.SA8D)
+    shape_res, line["sa8d_full_4k10"]["all_shapes"] = run_4k10(shape_jobs, 5)
+    line["sa8d_full_4k10"]["all_shapes"]["workload"] = "all 593 PUs of every 64x64 CTU (24 HEVC PU shapes, 64x64 .. 8x4 / 4x8), FULL +-16, SA8D"
     for i in ids4:
         eng.release_plane(i)
 
@@ -539,7 +548,12 @@ def main():
         ok = ok and bool(np.array_equal(chk, had_res[hsel]))
         asel = np.arange(len(had_jobs), len(all_jobs), 2503)
         chk, _ = o.search(seq4[1], [seq4[0]], all_jobs[asel], threads=8, bit_depth=10)
-        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, all_res[asel]))
+        ok = ok and bool(np.array_equal(chk, all_res[asel]))
+        ssel = np.arange(0, len(shape_jobs), 1201)
+        chk, _ = o.search(seq4[1], [seq4[0]], shape_jobs[ssel], threads=8, bit_depth=10)
+        line["sa8d_full_4k10"]["all_shapes"]["parity_sample"] = "%d of %d PUs (every 1201st) equal to the oracle: %s" % (
+            len(ssel), len(shape_jobs), bool(np.array_equal(chk, shape_res[ssel])))
+        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, shape_res[ssel]))
 
     print(json.dumps(line), flush=True)
 

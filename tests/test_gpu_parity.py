@@ -321,6 +321,33 @@ def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits,
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10)])
+@pytest.mark.parametrize("icost", [J.SA8D, J.SAD])
+def test_every_partition_of_the_ctus_through_the_shared_pass(eng, oracle, bits, depth, icost):
+    """All 593 PUs of every CTU (24 shapes, 64x64 down to 8x4 / 4x8, the asymmetric ones included) in one list, exhaustive
+    search: squares and partitions made of 8x8 cells with sa8d_inter's 8x8 / 16x16 recipe, those with 4- or 12-pixel
+    sides with its SATD recipe (4x4 tiles), all from one pass over each cell's window; the same with the SAD metric.
+    A picture with partial CTUs at the right and bottom edges (per-PU clipped ranges), a centred +-9 window, and a
+    +-5 window around a non-zero predictor with a sub-pel round behind it."""
+    W, H = 152, 136
+    fr = synth.make_sequence(W, H, 2, seed=123, bit_depth=depth)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    parts = [J.all_partition_jobs(W, H, method=J.FULL, subme=0, merange=9, qp=27, icost=icost),
+             J.all_partition_jobs(W, H, cu_sizes=(16, 8), method=J.FULL, subme=1, merange=5, qp=33, icost=icost, qmvp=(-9, 14))]
+    jobs = np.concatenate(parts)
+    assert len(J.all_partition_jobs(64, 64, method=J.FULL, subme=0, merange=1, qp=27)) == 593
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+    eng.eval_count(reset=True)
+    jl = eng.make_joblist(jobs, bytes_per_px=bits // 8)
+    got = jl.run(ids[0], [ids[1]])
+    jl.close()
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (len(bad), bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 @pytest.mark.parametrize("depth", [12, 14])
 def test_shared_pass_limits_fall_back_to_the_other_kernels(eng, oracle, depth):
     """What the candidate-per-lane exhaustive kernel does not take must come out right through the other kernels:

@@ -20,6 +20,10 @@ if "sa8d_full_4k10" in d:
         a = s["all_partitions"]
         print("  all %d partitions: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms" %
               (a["jobs_per_frame"], a["value"], a["ms_per_frame"], a["kernel_ms"], a["search_kernel_ms"]))
+    if "all_shapes" in s:
+        a = s["all_shapes"]
+        print("  all %d shapes' PUs: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms  %s" %
+              (a["jobs_per_frame"], a["value"], a["ms_per_frame"], a["kernel_ms"], a["search_kernel_ms"], a.get("parity_sample")))
 if "lookahead" in d:
     l = d["lookahead"]
     print("lookahead: %d pairs %.3f ms  (%.0f pairs/s, %.4g evals/s)  single pair %.3f ms  lowres init %.1f us  cpu %s  parity %s" %

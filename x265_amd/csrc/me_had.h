@@ -18,6 +18,13 @@
 // int16 for depths up to 10 bits), and the last horizontal stage folded into the sum of magnitudes by
 // |a + b| + |a - b| = 2 max(|a|, |b|).  No cross-lane traffic until a PU is complete; then its key
 // ((cost << 11) | candidate index inside the slab for 8x8 / 16x16, 64-bit above) is min-reduced across the wavefront.
+//
+// PUs with 4- or 12-pixel sides (8x4, 4x8 and the asymmetric partitions of a 16x16 CU: 16x4, 16x12, 4x16, 12x16) are
+// priced by sa8d_inter with the SATD recipe: sums of 4x4 Hadamard tiles, each tile (or 8x4 pair of tiles) halved
+// (common/pixel.cpp:187-274, table :756-826), which is exactly additive over 4x4 tiles because a tile's sum of
+// magnitudes is even.  The 8x8 transform factors as H8 = H2 (x) H4: the 4x4 transforms of a cell's four quadrants
+// followed by one more butterfly stage per direction.  Bundles with such PUs (HierBundle::quads) run the transform in
+// that order and take the four quadrant sums on the way; halves of a cell and strips of a 16x16 block follow from them.
 #pragma once
 
 #include "me_hier.h"
@@ -130,6 +137,87 @@ __device__ __forceinline__ uint32_t had8x8_half(const uint32_t (*rows)[4], const
     return sum;
 }
 
+// sum over both halves of max(|lo|, |hi|) of a packed pair: half the sum of magnitudes after the folded last stage
+__device__ __forceinline__ uint32_t had_fold_add(had_s2 q, uint32_t sum)
+{
+    const had_s2 m = __builtin_elementwise_max(q, -q);
+    uint32_t mu;
+    __builtin_memcpy(&mu, &m, 4);
+    const uint32_t mx = had_max_halves(mu);
+    had_u2 v, one = { 1, 0 };
+    __builtin_memcpy(&v, &mx, 4);
+    return __builtin_amdgcn_udot2(v, one, sum, false);
+}
+
+// had8x8_half with the butterfly stages reordered so that the 4x4 transforms of the cell's four quadrants exist
+// on the way: t[q] = sum of |4x4 Hadamard coefficients| / 2 of quadrant q (0 top left, 1 top right, 2 bottom left,
+// 3 bottom right) = satd_4x4 of that quadrant (common/pixel.cpp:187-213).  Returns the 8x8 sum / 2 as had8x8_half.
+__device__ __forceinline__ uint32_t had8x8_half_quads(const uint32_t (*rows)[4], const uint32_t *f, uint32_t *t)
+{
+    had_s2 a[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            a[r][c] = had_as_s2(rows[r][c]) - had_as_s2(f[4 * r + c]);
+    // inside the quadrants: vertical distances 2 and 1, horizontal distance 2 pixels = registers (0,1), (2,3)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+#pragma unroll
+        for (int d = 2; d >= 1; d >>= 1)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (!(r & d))
+                {
+                    const had_s2 s = a[r][c] + a[r + d][c], u = a[r][c] - a[r + d][c];
+                    a[r][c] = s;
+                    a[r + d][c] = u;
+                }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2)
+        {
+            const had_s2 s = a[r][c] + a[r][c + 1], u = a[r][c] - a[r][c + 1];
+            a[r][c] = s;
+            a[r][c + 1] = u;
+        }
+    // (horizontal distance 1 lives inside a register and is folded into the magnitudes)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+                sum = had_fold_add(a[4 * (q >> 1) + r][2 * (q & 1) + c], sum);
+        t[q] = sum;
+    }
+    // across the quadrants: vertical distance 4, horizontal distance 4 pixels = registers (0,2), (1,3)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const had_s2 s = a[r][c] + a[r + 4][c], u = a[r][c] - a[r + 4][c];
+            a[r][c] = s;
+            a[r + 4][c] = u;
+        }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+        {
+            sum = had_fold_add(a[r][c] + a[r][c + 2], sum);
+            sum = had_fold_add(a[r][c] - a[r][c + 2], sum);
+        }
+    return sum;
+}
+
 // 8 reference pixels starting at element `e` of LDS row `row` (dwords), as four 16-bit pairs
 template <typename PIX>
 __device__ __forceinline__ void had_load_row(const uint32_t *row, int e, uint32_t *out)
@@ -202,6 +290,50 @@ __device__ __forceinline__ void sad8x8_quad_u8(const uint32_t *wbase, int pitch,
     h[3] = (uint32_t)(acc >> 48);
 }
 
+// The SAD variants with one sum per quadrant of the cell: hq[q][c], q as in had8x8_half_quads, c = candidate
+__device__ __forceinline__ void sad8x8_pair_u16_quads(const uint32_t *wbase, int pitch, int e, const uint32_t *f, uint32_t (*hq)[2])
+{
+    const uint32_t *d = wbase + (e >> 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        hq[q][0] = hq[q][1] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+        uint32_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            w[k] = d[r * pitch + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int q = 2 * (r >> 2) + (k >> 1);
+            hq[q][0] = __builtin_amdgcn_sad_u16(w[k], f[4 * r + k], hq[q][0]);
+            hq[q][1] = __builtin_amdgcn_sad_u16(__builtin_amdgcn_alignbyte(w[k + 1], w[k], 2), f[4 * r + k], hq[q][1]);
+        }
+    }
+}
+__device__ __forceinline__ void sad8x8_quad_u8_quads(const uint32_t *wbase, int pitch, int e, const uint32_t *f, uint32_t (*hq)[4])
+{
+    unsigned long long acc[4] = { 0, 0, 0, 0 };
+    const uint32_t *d = wbase + (e >> 2);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+        const int q = 2 * (r >> 2);
+        acc[q] = __builtin_amdgcn_qsad_pk_u16_u8(lds_pair(d + r * pitch), f[2 * r], acc[q]);
+        acc[q + 1] = __builtin_amdgcn_qsad_pk_u16_u8(lds_pair(d + r * pitch + 1), f[2 * r + 1], acc[q + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        hq[q][0] = (uint32_t)acc[q] & 0xffffu;
+        hq[q][1] = (uint32_t)acc[q] >> 16;
+        hq[q][2] = (uint32_t)(acc[q] >> 32) & 0xffffu;
+        hq[q][3] = (uint32_t)(acc[q] >> 48);
+    }
+}
+
 // candidates per lane task: SAD: 2 (16-bit pixels) or 4 (8-bit); SA8D: 1
 __device__ __host__ constexpr int had_nc(bool sad, int bytes_per_px) { return !sad ? 1 : bytes_per_px == 2 ? 2 : 4; }
 
@@ -246,9 +378,9 @@ __device__ __forceinline__ void had_rect_value(int kind, const uint32_t (*S)[NC]
     }
 }
 
-template <typename PIX, bool MASK, bool SAD, bool RECTS>
+template <typename PIX, bool MASK, bool SAD, bool RECTS, bool QUADS>
 __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
-                                              const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
+                                              const XA_CONST uint32_t *pf, const HierQuads *QJ, FullBest *fb, int fb_stride, uint32_t *lds)
 {
     constexpr int PB = (int)sizeof(PIX), PPD = 4 / PB, NC = had_nc(SAD, PB);
     constexpr bool SAD8 = SAD && PB == 1;               // byte SADs: 16 encoder dwords per cell
@@ -267,13 +399,19 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
-    // bundles with rectangular PUs: 64-bit slots [waves][HIER_MAX_RECT]
+    // bundles with rectangular PUs: 64-bit slots [waves][HIER_MAX_RECT]; with PUs of 4- or 12-pixel sides: 32-bit
+    // slots [waves][HIER_QUAD_PUS] behind them (cell z, half k at 4 z + k; block q, partition k at 256 + 8 q + k)
     const int n_rect = RECTS ? B.rect_end[20] : 0;
+    const bool quads = QUADS && B.quads != 0;
     unsigned long long *s_rk = s_big + HAD_WAVES * 5;
+    uint32_t *s_qslot = (uint32_t*)(s_rk + (n_rect ? nwaves * HIER_MAX_RECT : 0));
     {
-        if (RECTS)
+        if (RECTS && n_rect)
             for (int i = tid; i < nwaves * HIER_MAX_RECT; i += nthreads)
                 s_rk[i] = ~0ull;
+        if (quads)
+            for (int i = tid; i < nwaves * HIER_QUAD_PUS; i += nthreads)
+                s_qslot[i] = ~0u;
         const uint8_t *r0 = (const uint8_t*)ref.origin;
         const int64_t lo = ref.lo, hi = ref.hi - PPD;
         const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + y_lo;
@@ -321,6 +459,14 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
 #pragma unroll
         for (int c = 0; c < NC; c++)
             q16[c] = a32[c] = a64[c] = 0;
+        // QUADS: strips of the running 16x16 block in SATD / SAD units: rows 0-3, rows 12-15, columns 0-3, columns 12-15, all
+        [[maybe_unused]] uint32_t bq[5][QUADS ? NC : 1];
+        if constexpr (QUADS)
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    bq[i][c] = 0;
         // is candidate c outside job jid's own range?
         auto kill = [&](int jid, int c) -> bool {
             if (!MASK)
@@ -410,7 +556,30 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             for (int e = 0; e < FDW; e++)
                 f[e] = fe[e];
             uint32_t h[NC];                                              // the cell's SAD, or S8 / 2
-            if constexpr (SAD8)
+            [[maybe_unused]] uint32_t hq[4][NC];                         // QUADS: the SADs / 4x4 SATDs of its four quadrants
+            if constexpr (QUADS)
+            {
+                if constexpr (SAD8)
+                    sad8x8_quad_u8_quads(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, hq);
+                else if constexpr (SAD)
+                    sad8x8_pair_u16_quads(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, hq);
+                else
+                {
+                    uint32_t rows[8][4], t[4];
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
+                    h[0] = had8x8_half_quads(rows, f, t);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        hq[q][0] = t[q];
+                }
+                if constexpr (SAD)
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        h[c] = hq[0][c] + hq[1][c] + hq[2][c] + hq[3][c];
+            }
+            else if constexpr (SAD8)
                 sad8x8_quad_u8(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, h);
             else if constexpr (SAD)
                 sad8x8_pair_u16(wbase + cy * 8 * pitch, pitch, x + cx * 8, f, h);
@@ -421,6 +590,40 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 for (int r = 0; r < 8; r++)
                     had_load_row<PIX>(wbase + (cy * 8 + r) * pitch, x + cx * 8, rows[r]);
                 h[0] = had8x8_half(rows, f);
+            }
+            if constexpr (QUADS)
+            {
+                if (quads)
+                {
+                    // halves of the cell
+                    const int32_t *cj = QJ->cell[z];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const int jid = cj[k];
+                        if (jid < 0)
+                            continue;
+                        const int qa = k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 0 : 1, qb = k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 2 : 3;
+                        uint32_t v[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            v[c] = hq[qa][c] + hq[qb][c];
+                        const uint32_t m = hier_wave_min_last(key32(jid, v));
+                        if (lane == 63)
+                            atomicMin(s_qslot + wv * HIER_QUAD_PUS + 4 * z + k, m);
+                    }
+                    // strips of the 16x16 block: its first / last 4 rows and columns, and everything
+                    const int zx = z & 1, zy = (z >> 1) & 1;
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                    {
+                        bq[0][c] += zy == 0 ? hq[0][c] + hq[1][c] : 0;
+                        bq[1][c] += zy == 1 ? hq[2][c] + hq[3][c] : 0;
+                        bq[2][c] += zx == 0 ? hq[0][c] + hq[2][c] : 0;
+                        bq[3][c] += zx == 1 ? hq[1][c] + hq[3][c] : 0;
+                        bq[4][c] += hq[0][c] + hq[1][c] + hq[2][c] + hq[3][c];
+                    }
+                }
             }
             uint32_t v8[NC];
 #pragma unroll
@@ -466,6 +669,35 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
                 const int q = z >> 2;
+                if constexpr (QUADS)
+                {
+                    if (quads)
+                    {
+                        // (a block with such PUs has all four cells covered)
+                        const int32_t *bj = QJ->blk[q];
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                        {
+                            const int jid = bj[k];
+                            if (jid < 0)
+                                continue;
+                            const int strip = k == 0 || k == 1 ? 0 : k == 2 || k == 3 ? 1 : k == 4 || k == 5 ? 2 : 3;
+                            const bool rest = k == 1 || k == 2 || k == 5 || k == 6;     // the 12-pixel part: everything but the strip
+                            uint32_t v[NC];
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                v[c] = rest ? bq[4][c] - bq[strip][c] : bq[strip][c];
+                            const uint32_t m = hier_wave_min_last(key32(jid, v));
+                            if (lane == 63)
+                                atomicMin(s_qslot + wv * HIER_QUAD_PUS + 256 + 8 * q + k, m);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 5; i++)
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                bq[i][c] = 0;
+                    }
+                }
                 uint32_t v16[NC];
 #pragma unroll
                 for (int c = 0; c < NC; c++)
@@ -610,12 +842,34 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
         fb[(size_t)B.rect[tid].job * fb_stride + it.slot] = f;
     }
+    if constexpr (QUADS)
+    {
+        if (quads)
+            for (int k = tid; k < HIER_QUAD_PUS; k += nthreads)
+            {
+                const int jid = k < 256 ? QJ->cell[k >> 2][k & 3] : QJ->blk[(k - 256) >> 3][(k - 256) & 7];
+                if (jid < 0)
+                    continue;
+                uint32_t m = ~0u;
+                for (int w = 0; w < nwaves; w++)
+                {
+                    const uint32_t v = s_qslot[w * HIER_QUAD_PUS + k];
+                    m = v < m ? v : m;
+                }
+                FullBest f;
+                const int ridx = m != ~0u ? y_lo * nxw + x_lo + (int)(m & ((1u << HAD_RIDX_BITS) - 1)) : -1;
+                f.cost = m != ~0u ? (int)(m >> HAD_RIDX_BITS) : 0x7fffffff;
+                f.mvx = ridx < 0 ? 0 : (int16_t)(B.mvx0 + ridx % nxw);
+                f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
+                fb[(size_t)jid * fb_stride + it.slot] = f;
+            }
+    }
 }
 
-template <typename PIX, bool RECTS>
+template <typename PIX, bool RECTS, bool QUADS>
 __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                               const HierItem *items, int n_items, const uint32_t *packed,
-                                                              FullBest *fb, int fb_stride)
+                                                              const HierQuads *quads, FullBest *fb, int fb_stride)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     const int id = blockIdx.x;
@@ -624,17 +878,18 @@ __global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, con
     const HierItem &it = items[id];
     const HierBundle &B = bundles[it.bundle];
     const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HAD_FENC_DW);
+    const HierQuads *qj = QUADS ? quads + it.bundle : nullptr;
     if (B.metric == X265AMD_SAD)
     {
         if (B.uniform)
-            had_item_body<PIX, false, true, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
+            had_item_body<PIX, false, true, RECTS, QUADS>(P, jobs, B, it, pf, qj, fb, fb_stride, lds);
         else
-            had_item_body<PIX, true, true, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
+            had_item_body<PIX, true, true, RECTS, QUADS>(P, jobs, B, it, pf, qj, fb, fb_stride, lds);
     }
     else if (B.uniform)
-        had_item_body<PIX, false, false, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        had_item_body<PIX, false, false, RECTS, QUADS>(P, jobs, B, it, pf, qj, fb, fb_stride, lds);
     else
-        had_item_body<PIX, true, false, RECTS>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        had_item_body<PIX, true, false, RECTS, QUADS>(P, jobs, B, it, pf, qj, fb, fb_stride, lds);
 }
 
 } // namespace xa

@@ -60,9 +60,20 @@ struct HierBundle
     // complete: rect_end[q], q = 0..15: PUs inside 16x16 block q (Z-order); rect_end[16 + b]: PUs of 32x32 block b;
     // rect_end[20]: PUs made of 16x16 values of the whole cell.  rect_end[g] = end of group g in rect[].
     int32_t  rect_end[21];
-    int32_t  pad2;
+    int32_t  quads;             // me_had.h only: the bundle has PUs with 4- or 12-pixel sides (their jobs: HierQuads of this bundle)
     struct Rect { int32_t job; uint32_t kind; } rect[HIER_MAX_RECT];
 };
+
+// The PUs of a bundle with 4- or 12-pixel sides (me_had.h), -1: no such job.  Per 8x8 cell z (Z-order) its halves:
+// 0 = 8x4 rows 0-3, 1 = 8x4 rows 4-7, 2 = 4x8 columns 0-3, 3 = 4x8 columns 4-7.  Per 16x16 block q (Z-order) the
+// asymmetric partitions: 0 = 16x4 at row 0, 1 = 16x12 at row 4, 2 = 16x12 at row 0, 3 = 16x4 at row 12,
+// 4 = 4x16 at column 0, 5 = 12x16 at column 4, 6 = 12x16 at column 0, 7 = 4x16 at column 12.
+struct HierQuads
+{
+    int32_t cell[64][4];
+    int32_t blk[16][8];
+};
+constexpr int HIER_QUAD_PUS = 64 * 4 + 16 * 8;
 
 // A work item: lane tasks [t_lo, t_hi) of a bundle, in raster order of (row quad, x group)
 struct HierItem

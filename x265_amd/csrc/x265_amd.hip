@@ -103,9 +103,10 @@ struct x265amd_joblist
     DevBuf  jobs, results, fb, items, item_jobs, idx, hist;
     DevBuf  hier_bundles, hier_items, hier_fenc;      // whole-cell bundles of the hierarchical exhaustive kernel
     int     n_hier_bundles = 0, n_hier_items = 0, hier_lds_bytes = 0;
-    DevBuf  had_bundles, had_items, had_fenc;         // the same for the Hadamard exhaustive kernel
+    DevBuf  had_bundles, had_items, had_fenc, had_quads;   // the same for the Hadamard exhaustive kernel (had_quads: HierQuads per bundle, if any)
     int     n_had_bundles = 0, n_had_items = 0, had_lds_bytes = 0, had_max_depth = 10, had_threads = 128;
     bool    had_rects = false;            // some bundle of the candidate-per-lane kernel has rectangular PUs
+    bool    had_quad_pus = false;         // some bundle has PUs with 4- or 12-pixel sides
     DevBuf  fb_jobs;                      // with Hadamard bundles: one flag per job, "an exhaustive kernel covers its integer stage"
     bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
@@ -542,7 +543,8 @@ void xcd_interleave(std::vector<T> &v)
 // planes up to 10 bits deep.  There a lane task is ONE candidate, a bundle may hold a single job (the
 // general kernel's scan is far slower), and a slab has at most 2^HAD_RIDX_BITS candidates.
 void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector<char> &in_bundle,
-               std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes, int *had_threads_out = nullptr)
+               std::vector<HierBundle> &bundles, std::vector<HierItem> &items, int &lds_bytes, int *had_threads_out = nullptr,
+               std::vector<HierQuads> *quads_out = nullptr)
 {
     lds_bytes = 0;
     if (!had && bpp != 1)
@@ -606,6 +608,30 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             }
         }
         return -1; };
+    // A partition of the cell (gx, gy) with a 4- or 12-pixel side (HierQuads in me_hier.h)?  Returns its slot: 4 z + k
+    // for the halves of cell z, 256 + 8 q + k for the asymmetric partitions of 16x16 block q; or -1.
+    auto quad_slot = [&](const x265amd_me_job &j, int gx, int gy) {
+        const int ox = j.pu_x - gx * 64, oy = j.pu_y - gy * 64, w = j.w, h = j.h;
+        if (ox < 0 || oy < 0 || ox + w > 64 || oy + h > 64)
+            return -1;
+        if (w == 8 && h == 4 && !(ox & 7) && !(oy & 3)) return 4 * zidx(ox >> 3, oy >> 3) + ((oy & 4) ? 1 : 0);
+        if (w == 4 && h == 8 && !(oy & 7) && !(ox & 3)) return 4 * zidx(ox >> 3, oy >> 3) + ((ox & 4) ? 3 : 2);
+        const int q = zidx(ox >> 3, oy >> 3) >> 2, rx = ox & 15, ry = oy & 15;
+        if (w == 16 && rx == 0)
+        {
+            if (h == 4 && ry == 0)   return 256 + 8 * q + 0;
+            if (h == 12 && ry == 4)  return 256 + 8 * q + 1;
+            if (h == 12 && ry == 0)  return 256 + 8 * q + 2;
+            if (h == 4 && ry == 12)  return 256 + 8 * q + 3;
+        }
+        if (h == 16 && ry == 0)
+        {
+            if (w == 4 && rx == 0)   return 256 + 8 * q + 4;
+            if (w == 12 && rx == 4)  return 256 + 8 * q + 5;
+            if (w == 12 && rx == 0)  return 256 + 8 * q + 6;
+            if (w == 4 && rx == 12)  return 256 + 8 * q + 7;
+        }
+        return -1; };
     std::map<std::tuple<int, int, int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < n; i++)
     {
@@ -614,7 +640,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             continue;
         const int gx = fl(j.pu_x), gy = fl(j.pu_y);
         int kind_unused;
-        if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy, kind_unused) >= 0))
+        if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy, kind_unused) >= 0) && !(had && quads_out && quad_slot(j, gx, gy) >= 0))
             continue;
         groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
     }
@@ -629,11 +655,27 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         double old_work = 0;
         std::vector<int> taken;
         std::vector<HierBundle::Rect> rects[21];
+        HierQuads QJ;
+        memset(&QJ, 0xff, sizeof(QJ));       // every job -1
         for (int i : g.second)
         {
             const x265amd_me_job &j = jobs[i];
             const int cx = (j.pu_x - gx * 64) >> 3, cy = (j.pu_y - gy * 64) >> 3, z = zidx(cx, cy);
-            if (is_square(j, gx, gy))
+            const int qs = had && quads_out ? quad_slot(j, gx, gy) : -1;
+            if (qs >= 0)
+            {
+                int32_t &slot = qs < 256 ? QJ.cell[qs >> 2][qs & 3] : QJ.blk[(qs - 256) >> 3][(qs - 256) & 7];
+                if (slot >= 0)
+                    continue;           // the same PU twice: the second one is scanned on its own
+                slot = i;
+                B.quads = 1;
+                if (qs < 256)
+                    B.cells |= 1ull << z;
+                else                    // the strips of a 16x16 block need its four cells
+                    for (int k = 0; k < 4; k++)
+                        B.cells |= 1ull << (4 * (z >> 2) + k);
+            }
+            else if (is_square(j, gx, gy))
             {
                 const int k = j.w == 8 ? z : j.w == 16 ? 64 + (z >> 2) : j.w == 32 ? 80 + (z >> 4) : 84;
                 if (B.job[k] >= 0)
@@ -726,7 +768,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
         const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
-                          (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0);
+                          (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0) + (B.quads ? 4 * (threads / 64) * HIER_QUAD_PUS : 0);
         bool fits = true;
         std::vector<HierItem> mine;
         for (int t = 0, slot = 0; t < ntasks; t += per, slot++)
@@ -750,9 +792,13 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         for (int i : taken)
             in_bundle[i] = 1;
         bundles.push_back(B);
+        if (quads_out)
+            quads_out->push_back(QJ);
         items.insert(items.end(), mine.begin(), mine.end());
         if (n_rect && had_threads_out)
             *had_threads_out |= 1 << 16;        // (bit 16: some bundle has rectangular PUs)
+        if (B.quads && had_threads_out)
+            *had_threads_out |= 1 << 17;        // (bit 17: some bundle has PUs with 4- or 12-pixel sides)
     }
     if (bundles.empty())
         lds_bytes = 0;
@@ -803,11 +849,14 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         plan_hier(jobs, n, bpp, false, in_bundle, hbundles, hitems, L->hier_lds_bytes);
     std::vector<HierBundle> dbundles;
     std::vector<HierItem> ditems;
+    std::vector<HierQuads> dquads;
     L->n_had_bundles = L->n_had_items = L->had_lds_bytes = 0;
     const std::vector<char> in_hier = in_bundle;
     if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the candidate-per-lane kernel off)
-        plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes, &L->had_threads);
-    L->had_rects = (L->had_threads >> 16) != 0;
+        plan_hier(jobs, n, bpp, true, in_bundle, dbundles, ditems, L->had_lds_bytes, &L->had_threads,
+                  (c->flags & 64) ? nullptr : &dquads);     // (bit 6: PUs with 4- or 12-pixel sides stay out of it)
+    L->had_rects = ((L->had_threads >> 16) & 1) != 0;
+    L->had_quad_pus = ((L->had_threads >> 17) & 1) != 0;
     L->had_threads &= 0xffff;
     if (!ditems.empty())
     {
@@ -818,6 +867,11 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         if (int rc = ensure(c, L->had_items, ditems.size() * sizeof(HierItem))) return rc;
         if (int rc = ensure(c, L->had_fenc, dbundles.size() * (size_t)HAD_FENC_DW * 4)) return rc;
         if (int rc = ensure(c, L->fb_jobs, 2 * (size_t)n)) return rc;
+        if (L->had_quad_pus)
+        {
+            if (int rc = ensure(c, L->had_quads, dquads.size() * sizeof(HierQuads))) return rc;
+            HIPCHK(c, hipMemcpyAsync(L->had_quads.p, dquads.data(), dquads.size() * sizeof(HierQuads), hipMemcpyHostToDevice, c->stream));
+        }
         L->had_max_depth = 12;
         for (const HierBundle &B : dbundles)
             if (B.metric != X265AMD_SAD)
@@ -929,7 +983,8 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
-                       &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->fb_jobs };
+                       &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->had_quads,
+                       &L->fb_jobs };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -970,20 +1025,22 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
     if (had)
     {
         hipStream_t st = c->lane(k++);
+#define XA_LAUNCH_HAD_V(PIX, RECTS, QUADS)                                                                         \
+        hipLaunchKernelGGL((k_full_had<PIX, RECTS, QUADS>), dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P, \
+                           (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,                  \
+                           (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,        \
+                           (const HierQuads*)L->had_quads.p, (FullBest*)L->fb.p, FB_STRIDE_PLAN)
 #define XA_LAUNCH_HAD(PIX)                                                                                         \
         hipLaunchKernelGGL(k_pack_fenc16<PIX>, dim3(L->n_had_bundles), dim3(256), 0, st, P,                        \
                            (const HierBundle*)L->had_bundles.p, L->n_had_bundles, (uint32_t*)L->had_fenc.p);       \
-        if (L->had_rects)                                                                                          \
-            hipLaunchKernelGGL((k_full_had<PIX, true>), dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P, \
-                               (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,              \
-                               (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,    \
-                               (FullBest*)L->fb.p, FB_STRIDE_PLAN);                                                \
+        if (L->had_quad_pus)                                                                                       \
+            XA_LAUNCH_HAD_V(PIX, true, true);                                                                      \
+        else if (L->had_rects)                                                                                     \
+            XA_LAUNCH_HAD_V(PIX, true, false);                                                                     \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_full_had<PIX, false>), dim3(L->n_had_items), dim3(L->had_threads), L->had_lds_bytes, st, P, \
-                               (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->had_bundles.p,              \
-                               (const HierItem*)L->had_items.p, L->n_had_items, (const uint32_t*)L->had_fenc.p,    \
-                               (FullBest*)L->fb.p, FB_STRIDE_PLAN)
+            XA_LAUNCH_HAD_V(PIX, false, false)
         if (L->bpp == 1) { XA_LAUNCH_HAD(uint8_t); } else { XA_LAUNCH_HAD(uint16_t); }
+#undef XA_LAUNCH_HAD_V
 #undef XA_LAUNCH_HAD
         HIPCHK(c, hipGetLastError());
     }

@@ -118,3 +118,26 @@ def full_search_evals(jobs: np.ndarray) -> int:
     nx = jobs["mvmax_x"].astype(np.int64) - jobs["mvmin_x"] + 1
     ny = jobs["mvmax_y"].astype(np.int64) - jobs["mvmin_y"] + 1
     return int((np.maximum(nx, 0) * np.maximum(ny, 0)).sum())
+
+
+def cu_partitions(n2: int):
+    """(ox, oy, w, h) of every PU an n2 x n2 CU can be cut into (reference: the PartSize loop of
+    TEncCu::xCompressCU, Lib/TLibEncoder/TEncCu.cpp; SIZE_2Nx2N, 2NxN, Nx2N, and for CUs of 16 pixels and
+    more the asymmetric 2NxnU / 2NxnD / nLx2N / nRx2N): 13 PUs, 5 for an 8x8 CU."""
+    h2, q = n2 // 2, n2 // 4
+    parts = [(0, 0, n2, n2), (0, 0, n2, h2), (0, h2, n2, h2), (0, 0, h2, n2), (h2, 0, h2, n2)]
+    if n2 >= 16:
+        parts += [(0, 0, n2, q), (0, q, n2, n2 - q), (0, 0, n2, n2 - q), (0, n2 - q, n2, q),
+                  (0, 0, q, n2), (q, 0, n2 - q, n2), (0, 0, n2 - q, n2), (n2 - q, 0, q, n2)]
+    return parts
+
+
+def all_partition_jobs(pic_w: int, pic_h: int, cu_sizes=(64, 32, 16, 8), **kw) -> np.ndarray:
+    """Every PU of every CU of the quadtree that lies fully inside the picture: 593 PUs per 64x64 CTU
+    (13 + 4 * 13 + 16 * 13 + 64 * 5) in 24 shapes from 64x64 down to 8x4 / 4x8."""
+    parts = []
+    for n2 in cu_sizes:
+        x, y = square_pu_grid(pic_w, pic_h, n2)
+        for (ox, oy, w, h) in cu_partitions(n2):
+            parts.append(make_jobs(pic_w, pic_h, x + ox, y + oy, w, h, **kw))
+    return np.concatenate(parts)
