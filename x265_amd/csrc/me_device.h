@@ -1538,6 +1538,55 @@ struct Dev
 
 // ------------------------------------------------------------------ caller side
 
+// Result of the dedicated exhaustive-search kernel for one job or one slab of candidate rows of
+// a job: the minimum of (cost, raster index) over the candidates it covered.
+struct FullBest
+{
+    int32_t cost;       // SAD + mvcost of the best raster candidate; INT32_MAX if none
+    int16_t mvx, mvy;   // full-pel
+};
+
+// Winner over the n (<= 16) slab partials of one job: lowest cost, then lowest raster index, as a serial raster scan
+// with strict `<` keeps it.  Lane s reads slot s; out of line, so that the kernel body keeps only uniform control flow.
+// Returns the cost in lane 0's x and the MV word (mvy << 16 | mvx & 0xffff) in y; cost INT32_MAX: no candidate.
+struct SlabBest { int cost, mv; };
+static __device__ __noinline__ SlabBest combine_slabs(const FullBest *fb, int n_, int nxr_, int minx_, int miny_)
+{
+    const int n = uni(n_), nxr = uni(nxr_), minx = uni(minx_), miny = uni(miny_);
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long key = ~0ull;
+    int mv = 0;
+    if (lane < n)
+    {
+        const FullBest f = fb[lane];
+        mv = ((int)f.mvy << 16) | ((int)f.mvx & 0xffff);
+        if (f.cost != 0x7fffffff)
+            key = ((unsigned long long)(uint32_t)f.cost << 32) | (uint32_t)((f.mvy - miny) * nxr + (f.mvx - minx));
+    }
+    unsigned long long m = key;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1)
+    {
+        const unsigned long long o = __shfl_xor(m, d);
+        m = o < m ? o : m;
+    }
+    m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    SlabBest r;
+    r.cost = 0x7fffffff;
+    r.mv = 0;
+    if (m != ~0ull)
+    {
+        const unsigned long long hit = __ballot(key == m);
+        r.cost = (int)(m >> 32);
+        r.mv = __shfl(mv, __builtin_ctzll(hit));
+    }
+    return r;
+}
+
+// the 8 neighbours of a refinement round / the square patterns (encoder/motion.cpp:124); entry 0 = the centre
+// (32-bit entries: uniform lookups then compile to scalar loads, which have no byte form on this target)
+static __constant__ int c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+
 // What the (scalar, inlined) search logic holds of a job: the LDS offset, the PU size, the MV-cost
 // context and the geometry of the LDS reference window - all in scalar registers.
 template <class L>
@@ -1816,6 +1865,44 @@ struct Wave
             fr[k] = phase(qx[k], qy[k]);
         }
         eval_n<8>(n, cx, cy, qx, qy, kind, fr, cflags, out);
+    }
+
+    // One refinement round (motion.cpp:799-809, 813-845, 851-861): the costs of the first n of the 8 neighbours of
+    // (bmx, bmy) at distance `step` (q-pel units), each subpelCompare + mvcost, in c[0 .. n).  Candidate data goes
+    // straight into the job state - no per-candidate arrays are kept in scalar registers.
+    __device__ __forceinline__ void round_costs(int bmx, int bmy, int step, int n, int kind, int *c)
+    {
+        // every candidate's block origin lies within [(bmv - step) >> 2, (bmv + step) >> 2]
+        const int where = lowres ? 0 : place((int)(int16_t)(bmx - step) >> 2, (int)(int16_t)(bmy - step) >> 2,
+                                             (int)(int16_t)(bmx + step) >> 2, (int)(int16_t)(bmy + step) >> 2, true);
+        // (only the first n entries: every evaluation path reads candidates below n, or repeats candidate 0)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            if (k >= 4 && n <= 4)
+                break;
+            const int qx = (int)(int16_t)(bmx + c_square1[k + 1][0] * step), qy = (int)(int16_t)(bmy + c_square1[k + 1][1] * step);
+            s->pts[k] = block_off(where, qx >> 2, qy >> 2);
+            s->lbl[k] = (qy << 16) | (qx & 0xffff);
+            s->frc[k] = phase(qx, qy);
+        }
+        evals += (unsigned)n;
+        const int cf = where | take_par(lowres ? 1 : n);
+        D::post(base, D::OP_ANY, n, cf, kind);
+        const Res8 r = D::call_any(base, n, cf, kind);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            c[k] = uni(r.c[k]);
+    }
+
+    // winner over the n (<= 16) slab partials of a job (combine_slabs), wave-uniform
+    __device__ __forceinline__ SlabBest slab_best(const FullBest *fb, int n, int nxr, int minx, int miny) const
+    {
+        const SlabBest sb = combine_slabs(fb, n, nxr, minx, miny);
+        SlabBest r;
+        r.cost = uni(sb.cost);
+        r.mv = uni(sb.mv);
+        return r;
     }
 
     // plain block cost against the block at the reference origin

@@ -19,6 +19,7 @@ struct BatchParams
     unsigned        *hist;                // optional: evaluations spent on job i, written to hist[i]
     const unsigned char *fb_jobs;         // optional: fb_jobs[i] != 0 = an exhaustive kernel ran job i's integer stage
                                           // (without it: exactly the jobs full_kernel_eligible accepts)
+    int32_t          lane_on;             // the smallest PUs run one job per QUAD of lanes (k_lane, me_lane.h), not in k_search
 };
 
 // The field checks every entry path applies to a job: the host entry points refuse a batch that fails them
@@ -69,9 +70,13 @@ __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
 // throughput wants the registers and wavefront slots a large PU's waiting workers hold; eight
 // alone).  `idx` (optional) lists the jobs of this launch; without it every job is visited and
 // those of the other classes are skipped.
-constexpr int JOB_CLASSES = 3;
+constexpr int JOB_CLASSES = 4;           // 0 .. 2: the general kernel's classes; LANE_CLASS: the quad-per-job kernel's jobs
+constexpr int LANE_CLASS = 3;
+constexpr int LANE_MAX_AREA = 64;        // PU pixels of a quad-per-job search (four 4x4 tiles): 8x8, 8x4, 4x8, 16x4, 4x16, 4x4, 12x4, 4x12
 constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-out)
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
+// Is job (w, h) one for the quad-per-job kernel?  (`lane_on`: the batch's references are full-resolution planes)
+__device__ __host__ inline bool lane_job(int w, int h, bool lane_on) { return lane_on && w * h <= LANE_MAX_AREA; }
 
 template <class L>
 __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::NW == 1 && L::INL ? 8 : 1))) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,
@@ -94,7 +99,8 @@ __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::N
         }
         return;
     }
-    if (job_class(j.w, j.h) != cls)
+    // (an index list names exactly this launch's jobs; without one every job is visited and the others are skipped)
+    if (!idx && (job_class(j.w, j.h) != cls || lane_job(j.w, j.h, P.lane_on != 0)))
         return;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];

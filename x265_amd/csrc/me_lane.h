@@ -1,0 +1,420 @@
+// Quad-per-job motion search for the smallest PUs (gfx950): FOUR LANES own one job, one 4x4 tile each.
+//
+// The general kernel (me_kernels.h, me_device.h) gives every job a wavefront and spreads the PU's 4-pixel
+// groups over its lanes: an 8x4 PU then uses 8 of 64 lanes and an 8x8 PU 16, while the scalar search logic,
+// the reductions and the calls cost the same as for a PU that fills the wavefront.  Here a PU of at most 64
+// pixels (8x8, 8x4, 4x8, 16x4, 4x16, ...) is at most four 4x4 tiles, and lane t of a quad of lanes takes tile t:
+// 16 jobs per wavefront.  The search itself (Search<> of me_search.h, the reference's encoder/motion.cpp:277-866)
+// runs as ordinary SIMT code, identically in the four lanes of a quad (they hold the same search state), and
+// differently from quad to quad.  A block cost is the lane's tile cost summed over the quad by two DPP
+// quad-permute adds:
+//   * sad                 v_sad_u8 / v_sad_u16 on the tile's four rows (common/pixel.cpp:78-95); the candidates of one
+//                         pattern step (sad_x3 / sad_x4 and the 6- and 8-point steps) are priced by ONE call whose
+//                         loads are all in flight together - a search is a chain of memory round trips, not of ALU work;
+//   * satd                4x4 Hadamard of the tile in the lane's registers, halved after the sum (exactly additive over
+//                         tiles: a tile's sum of magnitudes is even; common/pixel.cpp:187-274, table :652-722);
+//   * sa8d_inter          8x8: H8 = H2 (x) H4, so the quad's four 4x4 transforms get one more butterfly stage across
+//                         the lanes (DPP) per direction, rounded (S + 2) >> 2; every other shape of this class has a 4-
+//                         or 12-pixel side and takes the SATD recipe (common/pixel.cpp:276-362, table :756-826);
+//   * sub-pel candidates  the lane interpolates its tile with the same four 8-tap primitives as the general kernel
+//                         (Dev<>::h_pp / v_pp / h_ps / v_sp, common/ipfilter.cpp).
+// Every 4- or 12-pixel read is clamped into the plane allocation exactly like the general kernel's reads
+// (Dev<>::Src), so the two kernels agree bit for bit on every job, in-margin or not.
+//
+// Neighbouring quads hold neighbouring PUs (the planner orders this class by shape, search kind and picture
+// position), so a wavefront's row reads fall into a few cache lines and its quads mostly run the same loops.
+#pragma once
+
+#include "me_kernels.h"
+
+namespace xa {
+
+struct LaneCfg { static constexpr bool LR = false; };
+typedef int P8 __attribute__((ext_vector_type(8)));     // eight values in registers (a struct would travel through the stack)
+
+template <typename PIX>
+struct QuadWave
+{
+    typedef Dev<JobLds<PIX, 1, 64>> D;
+    static constexpr int DW = D::DW;
+
+    // per lane: the lane's tile of the job
+    const PIX *enc;                 // first pixel of the tile in the encoder plane
+    const PIX *ref;                 // the reference pixel under it (encoder/motion.cpp:288)
+    const uint16_t *cost;           // centre of the per-QP MV cost table
+    int estride, stride, gLo, gHi;  // [gLo, gHi): element offsets relative to `ref` of the whole padded allocation
+    int on;                         // the PU has a tile for this lane (else the lane repeats tile 0 and adds nothing)
+    int depth, w, h, mvpx, mvpy, ikind;
+    unsigned evals;
+    static constexpr bool lowres = false;
+
+    __device__ __forceinline__ void stamp(int) {}
+
+    __device__ __forceinline__ void bind(const PlaneDesc &e, const PlaneDesc &r, int pu_x, int pu_y, int w_, int h_, const uint16_t *cost_)
+    {
+        const int t = (int)(threadIdx.x & 3), ntx = w_ >> 2;
+        on = t < ((w_ * h_) >> 4);
+        const int tx = on ? (t % ntx) * 4 : 0, ty = on ? (t / ntx) * 4 : 0;
+        enc = (const PIX*)e.origin + (int64_t)(pu_y + ty) * e.stride + pu_x + tx;
+        estride = e.stride;
+        const int64_t tileOffset = (int64_t)(pu_y + ty) * r.stride + pu_x + tx;
+        ref = (const PIX*)r.origin + tileOffset;
+        stride = r.stride;
+        gLo = (int32_t)(r.lo - tileOffset);
+        gHi = (int32_t)(r.hi - tileOffset);
+        depth = DW == 1 ? 8 : r.depth;
+        w = w_; h = h_;
+        cost = cost_;
+        mvpx = mvpy = 0;
+        ikind = X265AMD_SAD;
+        evals = 0;
+    }
+    __device__ __forceinline__ void set_mvp(int x, int y) { mvpx = x; mvpy = y; }
+
+    // ---------------------------------------------------------------- helpers
+    static __device__ __forceinline__ int quad_sum(int v)
+    {
+        v += dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+        v += dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+        return v;
+    }
+    static __device__ __forceinline__ int clamp_off(int o, int len, int gLo, int gHi)
+    {
+        o = o < gLo ? gLo : o;
+        return o > gHi - len ? gHi - len : o;
+    }
+    static __device__ __forceinline__ void rd4(const PIX *p, uint32_t *r)
+    {
+        if (DW == 1)
+            r[0] = ld_u32(p);
+        else
+        {
+            const uint64_t v = ld_u64(p);
+            r[0] = (uint32_t)v;
+            r[1] = (uint32_t)(v >> 32);
+        }
+    }
+    static __device__ __forceinline__ int mv_cost(const uint16_t *cost, int mvp, int label, int cflags)
+    {
+        const int dx = (int16_t)((int16_t)label - (int16_t)mvp), dy = (int16_t)((label >> 16) - (mvp >> 16));
+        const XA_GLOBAL uint16_t *tab = (const XA_GLOBAL uint16_t*)(uintptr_t)cost;
+        const int a = tab[dx], b = tab[dy];
+        return (cflags & CF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
+    }
+
+    // ---------------------------------------------------------------- full-pel SADs of up to NB candidates in one call
+    // pos[k] = (y << 16) | (x & 0xffff): full-pel position measured; lbl[k]: q-pel label priced.  Entries >= n repeat
+    // entry 0 (their loads hit the same lines; their costs are not used).  All loads are issued before the first use.
+    template <int NB>
+    static __device__ __noinline__ P8 sad_multi(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi, int on,
+                                                const uint16_t *cost, int mvp, int cflags, P8 pos, P8 lbl)
+    {
+        uint32_t e[4][2], r[NB][4][2];
+        int mv[NB];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            rd4(enc + i * estride, e[i]);
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+        {
+            const int off = (pos[k] >> 16) * stride + (int)(int16_t)pos[k];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                rd4(ref + clamp_off(off + i * stride, 4, gLo, gHi), r[k][i]);
+            mv[k] = (cflags & CF_NOMV) ? 0 : mv_cost(cost, mvp, lbl[k], cflags);
+        }
+        P8 out = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+        {
+            uint32_t s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                if (DW == 1)
+                    s = __builtin_amdgcn_sad_u8(e[i][0], r[k][i][0], s);
+                else
+                    s = __builtin_amdgcn_sad_u16(e[i][1], r[k][i][1], __builtin_amdgcn_sad_u16(e[i][0], r[k][i][0], s));
+            }
+            out[k] = quad_sum(on ? (int)s : 0) + mv[k];
+        }
+        return out;
+    }
+
+    // ---------------------------------------------------------------- any kind, any q-pel position, one candidate
+    // 4x4 Hadamard of d in place (rows, then columns), no normalisation
+    static __device__ __forceinline__ void had4(int (*d)[4])
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int a0 = d[r][0] + d[r][1], a1 = d[r][0] - d[r][1], a2 = d[r][2] + d[r][3], a3 = d[r][2] - d[r][3];
+            d[r][0] = a0 + a2; d[r][1] = a1 + a3; d[r][2] = a0 - a2; d[r][3] = a1 - a3;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            const int a0 = d[0][c] + d[1][c], a1 = d[0][c] - d[1][c], a2 = d[2][c] + d[3][c], a3 = d[2][c] - d[3][c];
+            d[0][c] = a0 + a2; d[1][c] = a1 + a3; d[2][c] = a0 - a2; d[3][c] = a1 - a3;
+        }
+    }
+
+    // Cost of kind `kind` of the PU against the candidate at q-pel (qx, qy) (subpelCompare, encoder/motion.cpp:1140-1165;
+    // at a full-pel position the plain primitive) plus, unless CF_NOMV, the MV cost of the q-pel label.
+    static __device__ __noinline__ int cost_one(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi, int on,
+                                                int dwh, const uint16_t *cost, int mvp, int qx, int qy, int label, int kf)
+    {
+        const int depth = dwh & 0xff, w = (dwh >> 8) & 0xff, h = dwh >> 16;
+        const int kind = kf & 3, cflags = kf >> 2;
+        const int xf = qx & 3, yf = qy & 3;
+        const int off = (qy >> 2) * stride + (qx >> 2);
+        const int mv = (cflags & CF_NOMV) ? 0 : mv_cost(cost, mvp, label, cflags);
+        uint32_t e[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            rd4(enc + i * estride, e[i]);
+        // the lane's 4x4 tile of the prediction block
+        int p[4][4];
+        if (!xf && !yf)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                uint32_t d[2];
+                rd4(ref + clamp_off(off + i * stride, 4, gLo, gHi), d);
+                const P4 v = D::unpack4(d);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    p[i][c] = v.v[c];
+            }
+        }
+        else if (!yf)           // filterHorizontal_p_p
+        {
+            uint32_t px[4][6];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const PIX *q = ref + clamp_off(off + i * stride - 3, 12, gLo, gHi);
+#pragma unroll
+                for (int k = 0; k < 3 * DW; k++)
+                    px[i][k] = ld_u32((const uint8_t*)q + 4 * k);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                D::h_pp(px[i], xf, depth, p[i]);
+        }
+        else if (!xf)           // filterVertical_p_p
+        {
+            uint32_t rw[11][2];
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+            {
+                rw[k][1] = 0;
+                rd4(ref + clamp_off(off + (k - 3) * stride, 4, gLo, gHi), rw[k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                D::v_pp(rw + i, yf, depth, p[i]);
+        }
+        else                    // filterHorizontal_p_s over rows -3 .. 7, then filterVertical_s_p
+        {
+            uint32_t px[11][6], im[11][2];
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+            {
+                const PIX *q = ref + clamp_off(off + (k - 3) * stride - 3, 12, gLo, gHi);
+#pragma unroll
+                for (int i = 0; i < 3 * DW; i++)
+                    px[k][i] = ld_u32((const uint8_t*)q + 4 * i);
+            }
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+            {
+                int sm[4];
+                D::h_ps(px[k], xf, depth, sm);
+                im[k][0] = __builtin_amdgcn_perm((uint32_t)sm[1], (uint32_t)sm[0], 0x05040100);
+                im[k][1] = __builtin_amdgcn_perm((uint32_t)sm[3], (uint32_t)sm[2], 0x05040100);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                D::v_sp(im + i, yf, depth, p[i]);
+        }
+        int d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const P4 f = D::unpack4(e[i]);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                d[i][c] = on ? f.v[c] - p[i][c] : 0;
+        }
+        const int am = D::accum_mode(kind, w, h);
+        if (am >= 1)
+            had4(d);
+        if (am >= 2)
+        {
+            // the 8x8 transform = the four tiles' 4x4 transforms and one butterfly across the quad per direction
+            const bool hx = (threadIdx.x & 1) != 0, hy = (threadIdx.x & 2) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                {
+                    int v = d[i][c];
+                    const int px = dpp<0xB1>(v);
+                    v = hx ? px - v : v + px;
+                    const int py = dpp<0x4E>(v);
+                    d[i][c] = hy ? py - v : v + py;
+                }
+        }
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                s += d[i][c] < 0 ? -d[i][c] : d[i][c];
+        s = quad_sum(s);
+        if (am == 1)
+            s >>= 1;                            // every 4x4 sum of magnitudes is even
+        else if (am >= 2)
+            s = (s + 2) >> 2;                   // sa8d_8x8 (this class has no PU of 16x16 and more)
+        return s + mv;
+    }
+
+    __device__ __forceinline__ int cost_at(int qx, int qy, int lx, int ly, int kind, int cflags) const
+    {
+        return cost_one(enc, estride, ref, stride, gLo, gHi, on, depth | (w << 8) | (h << 16), cost,
+                        (mvpx & 0xffff) | (mvpy << 16), qx, qy, (lx & 0xffff) | (ly << 16), kind | (cflags << 2));
+    }
+
+    // ---------------------------------------------------------------- the interface Search<> drives (as Wave<>)
+    template <int N>
+    __device__ __forceinline__ void eval_points(const int *sx, const int *sy, const int *lx, const int *ly, int *out,
+                                                int pflags = 0, int shift3 = -1)
+    {
+        evals += (unsigned)N;
+        if (ikind == X265AMD_SAD)
+        {
+            constexpr int NB = N == 1 ? 1 : N <= 4 ? 4 : 8;
+            P8 pos, lbl;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int s = k < N ? k : 0, sh = (s == shift3) ? 3 : 2;
+                pos[k] = (sy[s] << 16) | (sx[s] & 0xffff);
+                lbl[k] = ((int)(int16_t)((int16_t)ly[s] << sh) << 16) | ((int)(int16_t)((int16_t)lx[s] << sh) & 0xffff);
+            }
+            const P8 c = sad_multi<NB>(enc, estride, ref, stride, gLo, gHi, on, cost, (mvpx & 0xffff) | (mvpy << 16), pflags, pos, lbl);
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                out[k] = c[k];
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            const int sh = (k == shift3) ? 3 : 2;
+            out[k] = cost_at(sx[k] * 4, sy[k] * 4, (int16_t)((int16_t)lx[k] << sh), (int16_t)((int16_t)ly[k] << sh), ikind, pflags);
+        }
+    }
+    __device__ __forceinline__ int cost_fpel(int mx, int my)
+    {
+        int c;
+        eval_points<1>(&mx, &my, &mx, &my, &c);
+        return c;
+    }
+    __device__ __forceinline__ int subpel_cost(int qx, int qy, int kind, bool with_mv)
+    {
+        evals++;
+        return cost_at(qx, qy, qx, qy, kind, with_mv ? 0 : CF_NOMV);
+    }
+    __device__ __forceinline__ void subpel_cost8(int n, const int *qx, const int *qy, int kind, int *out, int cflags = 0)
+    {
+        evals += (unsigned)n;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            out[k] = k < n ? cost_at(qx[k], qy[k], qx[k], qy[k], kind, (k == 0 && (cflags & CF_NOMV0)) ? CF_NOMV : 0) : 0;
+    }
+    // one refinement round: the first n of the 8 neighbours of (bmx, bmy) at distance `step`, each subpelCompare + mvcost
+    __device__ __forceinline__ void round_costs(int bmx, int bmy, int step, int n, int kind, int *c)
+    {
+        evals += (unsigned)n;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            c[k] = 0x7fffffff;
+            if (k < n)
+            {
+                const int qx = (int)(int16_t)(bmx + c_square1[k + 1][0] * step), qy = (int)(int16_t)(bmy + c_square1[k + 1][1] * step);
+                c[k] = cost_at(qx, qy, qx, qy, kind, 0);
+            }
+        }
+    }
+    // winner over a job's slab partials: lowest cost, then lowest raster index (see combine_slabs)
+    __device__ __forceinline__ SlabBest slab_best(const FullBest *fb, int n, int nxr, int minx, int miny) const
+    {
+        SlabBest r;
+        r.cost = 0x7fffffff;
+        r.mv = 0;
+        unsigned long long best = ~0ull;
+        for (int s = 0; s < n; s++)
+        {
+            const FullBest f = fb[s];
+            if (f.cost == 0x7fffffff)
+                continue;
+            const unsigned long long key = ((unsigned long long)(uint32_t)f.cost << 32) | (uint32_t)((f.mvy - miny) * nxr + (f.mvx - minx));
+            if (key < best)
+            {
+                best = key;
+                r.cost = f.cost;
+                r.mv = ((int)f.mvy << 16) | ((int)f.mvx & 0xffff);
+            }
+        }
+        return r;
+    }
+};
+
+// Sixteen jobs per wavefront: quad q of workgroup b takes job idx[16 b + q] (or job 16 b + q without an index list,
+// skipping the jobs of the general kernel's classes).
+template <typename PIX>
+__global__ void __launch_bounds__(64) k_lane(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n,
+                                             const FullBest *fb, int fb_stride, x265amd_me_result *out, unsigned long long *evals)
+{
+    const int slot = (int)(blockIdx.x * 16 + (threadIdx.x >> 2));
+    unsigned n_evals = 0;
+    if (slot < n)
+    {
+        const int id = idx ? idx[slot] : slot;
+        JobRegs j;
+        j.load(jobs + id);
+        const bool valid = idx || job_fields_valid(j, P.n_refs);
+        if (valid && lane_job(j.w, j.h, true))
+        {
+            const PlaneDesc &enc = P.planes[P.enc_plane];
+            const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
+            QuadWave<PIX> W;
+            W.bind(enc, ref, j.pu_x, j.pu_y, j.w, j.h, P.cost[j.qp]);
+            Search<LaneCfg, QuadWave<PIX>> S(W, j);
+            int ox, oy;
+            const bool covered = P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(PIX));
+            const FullBest *f = (fb && covered) ? fb + (size_t)id * fb_stride : nullptr;
+            const int cost = S.run(f, fb_stride, ox, oy);
+            if ((threadIdx.x & 3) == 0)
+            {
+                x265amd_me_result r;
+                r.mvx = (int16_t)ox;
+                r.mvy = (int16_t)oy;
+                r.cost = cost;
+                out[id] = r;
+                n_evals = W.evals;
+                if (P.hist)
+                    P.hist[id] = n_evals;
+            }
+        }
+    }
+    const int total = wave_sum((int)n_evals);
+    if (threadIdx.x == 0 && total)
+        atomicAdd(evals + (blockIdx.x % EVAL_SLOTS) * 16, (unsigned long long)(unsigned)total);
+}
+
+} // namespace xa

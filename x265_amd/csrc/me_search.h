@@ -12,54 +12,8 @@
 
 namespace xa {
 
-// Result of the dedicated exhaustive-search kernel for one job or one slab of candidate rows of
-// a job: the minimum of (cost, raster index) over the candidates it covered.
-struct FullBest
-{
-    int32_t cost;       // SAD + mvcost of the best raster candidate; INT32_MAX if none
-    int16_t mvx, mvy;   // full-pel
-};
-
-// Winner over the n (<= 16) slab partials of one job: lowest cost, then lowest raster index, as a serial raster scan
-// with strict `<` keeps it.  Lane s reads slot s; out of line, so that the kernel body keeps only uniform control flow.
-// Returns the cost in lane 0's x and the MV word (mvy << 16 | mvx & 0xffff) in y; cost INT32_MAX: no candidate.
-struct SlabBest { int cost, mv; };
-static __device__ __noinline__ SlabBest combine_slabs(const FullBest *fb, int n_, int nxr_, int minx_, int miny_)
-{
-    const int n = uni(n_), nxr = uni(nxr_), minx = uni(minx_), miny = uni(miny_);
-    const int lane = (int)(threadIdx.x & 63);
-    unsigned long long key = ~0ull;
-    int mv = 0;
-    if (lane < n)
-    {
-        const FullBest f = fb[lane];
-        mv = ((int)f.mvy << 16) | ((int)f.mvx & 0xffff);
-        if (f.cost != 0x7fffffff)
-            key = ((unsigned long long)(uint32_t)f.cost << 32) | (uint32_t)((f.mvy - miny) * nxr + (f.mvx - minx));
-    }
-    unsigned long long m = key;
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1)
-    {
-        const unsigned long long o = __shfl_xor(m, d);
-        m = o < m ? o : m;
-    }
-    m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-    SlabBest r;
-    r.cost = 0x7fffffff;
-    r.mv = 0;
-    if (m != ~0ull)
-    {
-        const unsigned long long hit = __ballot(key == m);
-        r.cost = (int)(m >> 32);
-        r.mv = __shfl(mv, __builtin_ctzll(hit));
-    }
-    return r;
-}
-
 // (32-bit entries: uniform lookups then compile to scalar loads, which have no byte form on this target)
 static __constant__ int c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-static __constant__ int c_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
 static __constant__ int c_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
                                       { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
 static __constant__ int c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
@@ -108,14 +62,16 @@ struct JobRegs
     }
 };
 
-template <class L>
+// WV: what prices candidates - Wave<L> (one PU per workgroup, pixels spread over the lanes; every value here is then
+// wave-uniform) or LaneWave<> of me_lane.h (one PU per lane; every value here is then per lane).
+template <class L, class WV = Wave<L>>
 struct Search
 {
-    Wave<L> &W;
+    WV &W;
     const JobRegs &j;
     int bmx, bmy, bcost;
 
-    __device__ __forceinline__ Search(Wave<L> &w_, const JobRegs &j_) : W(w_), j(j_) {}
+    __device__ __forceinline__ Search(WV &w_, const JobRegs &j_) : W(w_), j(j_) {}
 
     __device__ __forceinline__ bool in_range(int x, int y) const   // MV::checkRange, common/mv.h:96-99
     {
@@ -463,8 +419,8 @@ struct Search
             // minimum in raster order, which is what strict-`<` updates would have kept
             // combine the slabs: lowest cost, then lowest raster index
             const int nxr = j.mvmax_x - j.mvmin_x + 1;
-            const SlabBest sb = combine_slabs(fb, fb_stride > 16 ? 16 : fb_stride, nxr, j.mvmin_x, j.mvmin_y);
-            const int fcost = uni(sb.cost), fmv = uni(sb.mv), fx = XA_S16(fmv & 0xffff), fy = XA_S16(fmv >> 16);
+            const SlabBest sb = W.slab_best(fb, fb_stride > 16 ? 16 : fb_stride, nxr, j.mvmin_x, j.mvmin_y);
+            const int fcost = sb.cost, fmv = sb.mv, fx = XA_S16(fmv & 0xffff), fy = XA_S16(fmv >> 16);
             if (fcost < bcost)
             {
                 bcost = fcost;
@@ -544,33 +500,15 @@ struct Search
     // per-candidate arrays are kept in scalar registers.
     __device__ __forceinline__ int subpel_round(int step, int n, int kind)
     {
-        typedef Dev<L> D;
-        // every candidate's block origin lies within [(bmv - step) >> 2, (bmv + step) >> 2]
-        const int where = W.lowres ? 0 : W.place(XA_S16(bmx - step) >> 2, XA_S16(bmy - step) >> 2,
-                                                 XA_S16(bmx + step) >> 2, XA_S16(bmy + step) >> 2, true);
-        // (only the first n entries: every evaluation path reads candidates below n, or repeats candidate 0)
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-        {
-            if (k >= 4 && n <= 4)
-                break;
-            const int qx = XA_S16(bmx + c_square1[k + 1][0] * step), qy = XA_S16(bmy + c_square1[k + 1][1] * step);
-            W.s->pts[k] = W.block_off(where, qx >> 2, qy >> 2);
-            W.s->lbl[k] = (qy << 16) | (qx & 0xffff);
-            W.s->frc[k] = W.phase(qx, qy);
-        }
-        W.evals += (unsigned)n;
-        const int cf = where | W.take_par(W.lowres ? 1 : n);
-        D::post(W.base, D::OP_ANY, n, cf, kind);
-        const Res8 r = D::call_any(W.base, n, cf, kind);
+        int c[8];
+        W.round_costs(bmx, bmy, step, n, kind, c);
         int bdir = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const int c = uni(r.c[k]);
-            if (k < n && c < bcost)
+            if (k < n && c[k] < bcost)
             {
-                bcost = c;
+                bcost = c[k];
                 bdir = k + 1;
             }
         }

@@ -6,6 +6,7 @@
 #include "me_had.h"
 #include "me_lowres.h"
 #include "me_field.h"
+#include "me_lane.h"
 
 // (the general search, field and lookahead kernels are instantiated in x265_amd_part.hip)
 #define XA_INST extern template
@@ -112,7 +113,7 @@ struct x265amd_joblist
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
     bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
-    int     cls_count[JOB_CLASSES] = { 0, 0, 0 };   // job classes of the general kernel: idx = [class 0..., class 1..., class 2...]
+    int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., lane-per-job class ...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
 };
@@ -317,16 +318,24 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+    // the smallest PUs: one job per quad of lanes (full-resolution references), else the general kernel's smallest class
+    if (cnt[LANE_CLASS] > 0 && P.lane_on)
+        hipLaunchKernelGGL(k_lane<PIX>, dim3((cnt[LANE_CLASS] + 15) / 16), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[LANE_CLASS], cnt[LANE_CLASS],
+                           fb, fb_stride, d_out, c->d_evals);
+    else if (cnt[LANE_CLASS] > 0 && idx[LANE_CLASS])
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[LANE_CLASS]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[LANE_CLASS],
+                           cnt[LANE_CLASS], 0, fb, fb_stride, d_out, c->d_evals);
 }
 
-int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
+int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd_me_job *d_jobs, int n,
                    const int *idx_base, const int *cls_count,
                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool timing_events = true)
 {
     if (c->timing && timing_events)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr };
-    int cnt[JOB_CLASSES] = { n, n, n };
+    const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr, nullptr };
+    int cnt[JOB_CLASSES] = { n, n, n, n };
+    BatchParams P = P0;
     if (idx_base)
     {
         int off = 0;
@@ -338,12 +347,13 @@ int launch_general(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_
         }
     }
     // with index lists every launch has work: run the classes side by side
-    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0)) : 1;
+    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0)) : 1;
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     bool lr = false;
     for (int i = 0; i < P.n_refs; i++)
         lr = lr || c->h_planes[P.ref_planes[i]].lr_step != 0;
+    P.lane_on = !lr && !(c->flags & 128);       // (tuning aid: X265AMD_FLAGS bit 7 keeps the smallest PUs in the general kernel)
     if (bpp == 1 && !lr)
         launch_classes<uint8_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else if (bpp == 1)
@@ -820,15 +830,40 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         {
             std::vector<int> seg;
             for (int i = 0; i < n; i++)
-                if (job_class(jobs[i].w, jobs[i].h) == cls)
+                if ((lane_job(jobs[i].w, jobs[i].h, true) ? LANE_CLASS : job_class(jobs[i].w, jobs[i].h)) == cls)
                     seg.push_back(i);
             L->cls_count[cls] = (int)seg.size();
             if (!(c->flags & 8))        // (tuning aid: X265AMD_FLAGS bit 3 keeps the caller's job order)
             {
-                std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
-                    return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
-                           std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
-                xcd_interleave(seg);
+                if (cls == LANE_CLASS)
+                {
+                    // one job per quad of lanes: a wavefront takes 16 consecutive entries.  Jobs of one shape and search kind
+                    // together (the quads of a wavefront then run the same loops), each group in picture order (their
+                    // row reads share cache lines); whole wavefronts are dealt to the XCDs
+                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                        const x265amd_me_job &x = jobs[a], &y = jobs[b];
+                        return std::make_tuple((int)x.ref_idx, (int)x.method, (int)x.subme, (int)x.w, (int)x.h, x.pu_y, x.pu_x) <
+                               std::make_tuple((int)y.ref_idx, (int)y.method, (int)y.subme, (int)y.w, (int)y.h, y.pu_y, y.pu_x); });
+                    std::vector<std::vector<int>> chunks;
+                    for (size_t a = 0; a < seg.size(); a += 16)
+                        chunks.emplace_back(seg.begin() + a, seg.begin() + std::min(seg.size(), a + 16));
+                    // (only whole chunks may move: the last, partial one stays last)
+                    std::vector<std::vector<int>> whole(chunks.begin(), chunks.end() - (chunks.empty() || chunks.back().size() == 16 ? 0 : 1));
+                    xcd_interleave(whole);
+                    std::vector<int> flat;
+                    for (auto &ch : whole)
+                        flat.insert(flat.end(), ch.begin(), ch.end());
+                    if (!chunks.empty() && chunks.back().size() != 16)
+                        flat.insert(flat.end(), chunks.back().begin(), chunks.back().end());
+                    seg.swap(flat);
+                }
+                else
+                {
+                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                        return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
+                               std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
+                    xcd_interleave(seg);
+                }
             }
             order.insert(order.end(), seg.begin(), seg.end());
         }

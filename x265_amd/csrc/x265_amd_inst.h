@@ -1,6 +1,6 @@
 // The heavy kernel instantiations (general search, predictor-chained field, lookahead), listed once:
 // x265_amd.hip declares them `extern template` and x265_amd_part.hip defines one group of them per
-// translation unit (-DXA_PART=1..5), so the groups compile side by side (x265_amd/build.py).
+// translation unit (-DXA_PART=1..6), so the groups compile side by side (x265_amd/build.py).
 // XA_INST is `extern template` or `template`; XA_PART (optional) selects a group.
 #define XA_K_SEARCH(PIX, NW, MAXG, LR, INL)                                                                              \
     XA_INST __global__ void xa::k_search<xa::JobLds<PIX, NW, MAXG, LR, INL>>(xa::BatchParams, const x265amd_me_job*, const int*, \
@@ -21,6 +21,12 @@
     XA_INST __global__ void xa::k_lookahead<xa::JobLds<PIX, 1, 64, true, true>>(const xa::PlaneDesc*, const uint16_t*,    \
                                                                               const xa::LookPair*, int, int, int, int, int, int, int, \
                                                                               x265amd_me_result*, int*, unsigned long long*);
+#define XA_K_LANE(PIX)                                                                                                   \
+    XA_INST __global__ void xa::k_lane<PIX>(xa::BatchParams, const x265amd_me_job*, const int*, int, const xa::FullBest*, int, \
+                                            x265amd_me_result*, unsigned long long*);
+#if !defined(XA_PART) || XA_PART == 6
+XA_K_LANE(uint8_t) XA_K_LANE(uint16_t)
+#endif
 #if !defined(XA_PART) || XA_PART == 1
 XA_K_SEARCH_BIG(uint8_t)
 #endif
@@ -43,3 +49,4 @@ XA_K_LOOK(uint8_t) XA_K_LOOK(uint16_t)
 #undef XA_K_SEARCH_SMALL
 #undef XA_K_FIELD
 #undef XA_K_LOOK
+#undef XA_K_LANE
