@@ -1867,6 +1867,9 @@ struct Wave
         eval_n<8>(n, cx, cy, qx, qy, kind, fr, cflags, out);
     }
 
+    // entry [i][c] of one of the search's small tables (me_search.h): uniform indices, scalar loads from constant memory
+    template <int TAB> static __device__ __forceinline__ int tab(int i, int c);
+
     // One refinement round (motion.cpp:799-809, 813-845, 851-861): the costs of the first n of the 8 neighbours of
     // (bmx, bmy) at distance `step` (q-pel units), each subpelCompare + mvcost, in c[0 .. n).  Candidate data goes
     // straight into the job state - no per-candidate arrays are kept in scalar registers.

@@ -30,6 +30,40 @@
 namespace xa {
 
 struct LaneCfg { static constexpr bool LR = false; };
+
+// The search's small tables as 4-bit immediates: column c of a table of up to 16 rows in one 64-bit constant, entries
+// biased by +4 (all lie in [-4, 8]); a lookup is a shift and a mask instead of a per-lane memory read.
+template <int N, int M>
+constexpr uint64_t nib_pack(const int (&t)[N][M], int c)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < N; i++)
+        v |= (uint64_t)((t[i][c] + 4) & 15) << (4 * i);
+    return v;
+}
+constexpr int k_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+constexpr int k_hex2[8][2] = XA_T_HEX2;
+constexpr int k_hex4[16][2] = XA_T_HEX4;
+constexpr int k_star[16][2] = XA_T_STAR;
+constexpr int k_workload[8][5] = XA_T_WORKLOAD;
+constexpr int k_refine_h[9][2] = XA_T_REFINE_H;
+constexpr int k_refine_q[9][2] = XA_T_REFINE_Q;
+constexpr int k_range_mul[4][4] = XA_T_RANGE_MUL;
+template <int TAB> constexpr uint64_t nib_table(int c)
+{
+    return TAB == T_SQUARE1 ? nib_pack(k_square1, c) : TAB == T_HEX2 ? nib_pack(k_hex2, c) : TAB == T_HEX4 ? nib_pack(k_hex4, c) :
+           TAB == T_STAR ? nib_pack(k_star, c) : TAB == T_WORKLOAD ? nib_pack(k_workload, c) : TAB == T_REFINE_H ? nib_pack(k_refine_h, c) :
+           TAB == T_REFINE_Q ? nib_pack(k_refine_q, c) : 0;
+}
+// (range_mul is indexed [i][c] with both variable: its 16 entries in one constant)
+constexpr uint64_t nib_range_mul()
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 4; i++)
+        for (int c = 0; c < 4; c++)
+            v |= (uint64_t)((k_range_mul[i][c] + 4) & 15) << (4 * (4 * i + c));
+    return v;
+}
 typedef int P8 __attribute__((ext_vector_type(8)));     // eight values in registers (a struct would travel through the stack)
 
 template <typename PIX>
@@ -49,6 +83,16 @@ struct QuadWave
     static constexpr bool lowres = false;
 
     __device__ __forceinline__ void stamp(int) {}
+
+    template <int TAB> static __device__ __forceinline__ int tab(int i, int c)
+    {
+        if (TAB == T_RANGE_MUL)
+            return (int)((nib_range_mul() >> (4 * (4 * i + c))) & 15) - 4;
+        constexpr uint64_t c0 = nib_table<TAB>(0), c1 = nib_table<TAB>(1), c2 = TAB == T_WORKLOAD ? nib_table<TAB>(2) : 0,
+                           c3 = TAB == T_WORKLOAD ? nib_table<TAB>(3) : 0, c4 = TAB == T_WORKLOAD ? nib_table<TAB>(4) : 0;
+        const uint64_t t = c == 0 ? c0 : c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4;
+        return (int)((t >> (4 * i)) & 15) - 4;
+    }
 
     __device__ __forceinline__ void bind(const PlaneDesc &e, const PlaneDesc &r, int pu_x, int pu_y, int w_, int h_, const uint16_t *cost_)
     {
@@ -345,31 +389,51 @@ struct QuadWave
             c[k] = 0x7fffffff;
             if (k < n)
             {
-                const int qx = (int)(int16_t)(bmx + c_square1[k + 1][0] * step), qy = (int)(int16_t)(bmy + c_square1[k + 1][1] * step);
+                const int qx = (int)(int16_t)(bmx + tab<T_SQUARE1>(k + 1, 0) * step), qy = (int)(int16_t)(bmy + tab<T_SQUARE1>(k + 1, 1) * step);
                 c[k] = cost_at(qx, qy, qx, qy, kind, 0);
             }
         }
     }
-    // winner over a job's slab partials: lowest cost, then lowest raster index (see combine_slabs)
+    // winner over a job's slab partials: lowest cost, then lowest raster index (see combine_slabs).  Lane t of the quad
+    // reads slabs t, t + 4, ... (all loads in flight together); the quad's minimum goes to its four lanes.
     __device__ __forceinline__ SlabBest slab_best(const FullBest *fb, int n, int nxr, int minx, int miny) const
     {
-        SlabBest r;
-        r.cost = 0x7fffffff;
-        r.mv = 0;
-        unsigned long long best = ~0ull;
-        for (int s = 0; s < n; s++)
+        const int t = (int)(threadIdx.x & 3);
+        FullBest f[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
         {
-            const FullBest f = fb[s];
-            if (f.cost == 0x7fffffff)
-                continue;
-            const unsigned long long key = ((unsigned long long)(uint32_t)f.cost << 32) | (uint32_t)((f.mvy - miny) * nxr + (f.mvx - minx));
-            if (key < best)
-            {
-                best = key;
-                r.cost = f.cost;
-                r.mv = ((int)f.mvy << 16) | ((int)f.mvx & 0xffff);
-            }
+            const int s = t + 4 * k;
+            f[k] = fb[s < n ? s : 0];
+            if (s >= n)
+                f[k].cost = 0x7fffffff;
         }
+        // (cost, raster index) as two words; a slab without candidates has cost INT32_MAX and loses to every other
+        uint32_t bc = 0x7fffffffu, bi = ~0u;
+        int bm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t c = (uint32_t)f[k].cost, i = (uint32_t)((f[k].mvy - miny) * nxr + (f[k].mvx - minx));
+            const bool better = f[k].cost != 0x7fffffff && (c < bc || (c == bc && i < bi));
+            bc = better ? c : bc;
+            bi = better ? i : bi;
+            bm = better ? (((int)f[k].mvy << 16) | ((int)f[k].mvx & 0xffff)) : bm;
+        }
+#pragma unroll
+        for (int step = 0; step < 2; step++)
+        {
+            const uint32_t oc = (uint32_t)(step ? dpp<0x4E>((int)bc) : dpp<0xB1>((int)bc));
+            const uint32_t oi = (uint32_t)(step ? dpp<0x4E>((int)bi) : dpp<0xB1>((int)bi));
+            const int om = step ? dpp<0x4E>(bm) : dpp<0xB1>(bm);
+            const bool better = oc < bc || (oc == bc && oi < bi);
+            bc = better ? oc : bc;
+            bi = better ? oi : bi;
+            bm = better ? om : bm;
+        }
+        SlabBest r;
+        r.cost = (int)bc;
+        r.mv = bc == 0x7fffffffu ? 0 : bm;
         return r;
     }
 };

@@ -12,19 +12,39 @@
 
 namespace xa {
 
-// (32-bit entries: uniform lookups then compile to scalar loads, which have no byte form on this target)
-static __constant__ int c_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-static __constant__ int c_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
-                                      { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
-static __constant__ int c_star_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
-                                              { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+// The search's small tables (encoder/motion.cpp:51-60, 122-143; Lib/TLibEncoder/TEncSearch.cpp:59-83).  Two images of each:
+// a __constant__ array for the wave-uniform kernels (32-bit entries: uniform lookups then compile to scalar loads, which
+// have no byte form on this target) and a constexpr copy from which the per-lane kernel (me_lane.h) packs 4-bit
+// immediates - a per-lane table lookup would be a memory round trip in the middle of a dependent chain.
+// (c_square1 lives in me_device.h.)
+#define XA_T_HEX2 { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } }
+#define XA_T_HEX4 { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 }, \
+                    { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } }
+#define XA_T_STAR { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 }, \
+                    { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } }
 // workload[] (motion.cpp:51-60): hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd
-static __constant__ int c_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
-                                         { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+#define XA_T_WORKLOAD { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 }, \
+                        { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } }
 // s_mvRefineHpel / s_mvRefineQPel (Lib/TLibEncoder/TEncSearch.cpp:59-83): the two 9-point orders differ
-static __constant__ int c_refine_hpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
-static __constant__ int c_refine_qpel[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
-static __constant__ int c_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+#define XA_T_REFINE_H { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } }
+#define XA_T_REFINE_Q { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } }
+#define XA_T_RANGE_MUL { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } }
+static __constant__ int c_hex2[8][2] = XA_T_HEX2;
+static __constant__ int c_hex4[16][2] = XA_T_HEX4;
+static __constant__ int c_star_offsets[16][2] = XA_T_STAR;
+static __constant__ int c_workload[8][5] = XA_T_WORKLOAD;
+static __constant__ int c_refine_hpel[9][2] = XA_T_REFINE_H;
+static __constant__ int c_refine_qpel[9][2] = XA_T_REFINE_Q;
+static __constant__ int c_range_mul[4][4] = XA_T_RANGE_MUL;
+enum { T_SQUARE1, T_HEX2, T_HEX4, T_STAR, T_WORKLOAD, T_REFINE_H, T_REFINE_Q, T_RANGE_MUL };
+
+template <class L> template <int TAB>
+__device__ __forceinline__ int Wave<L>::tab(int i, int c)
+{
+    return TAB == T_SQUARE1 ? c_square1[i][c] : TAB == T_HEX2 ? c_hex2[i][c] : TAB == T_HEX4 ? c_hex4[i][c] :
+           TAB == T_STAR ? c_star_offsets[i][c] : TAB == T_WORKLOAD ? c_workload[i][c] : TAB == T_REFINE_H ? c_refine_hpel[i][c] :
+           TAB == T_REFINE_Q ? c_refine_qpel[i][c] : c_range_mul[i][c];
+}
 
 #define XA_S16(v) ((int)(int16_t)(v))
 
@@ -73,6 +93,9 @@ struct Search
 
     __device__ __forceinline__ Search(WV &w_, const JobRegs &j_) : W(w_), j(j_) {}
 
+    // table entry [i][c] (c is a constant at every call site)
+    template <int TAB> static __device__ __forceinline__ int tab(int i, int c) { return WV::template tab<TAB>(i, c); }
+
     __device__ __forceinline__ bool in_range(int x, int y) const   // MV::checkRange, common/mv.h:96-99
     {
         return x >= j.mvmin_x && x <= j.mvmax_x && y >= j.mvmin_y && y <= j.mvmax_y;
@@ -112,15 +135,15 @@ struct Search
 
     // N candidates (cx,cy) + d[k], all relative to one centre, in order; returns index of the last taken or -1.
     // Only the cost is updated; the caller moves bmv (pattern loops move after the whole set).
-    template <int N>
-    __device__ __forceinline__ int probe(int cx, int cy, const int (*d)[2])
+    template <int N, int TAB>
+    __device__ __forceinline__ int probe(int cx, int cy, int first)
     {
         int x[N], y[N], c[N], last = -1;
 #pragma unroll
         for (int k = 0; k < N; k++)
         {
-            x[k] = XA_S16(cx + d[k][0]);
-            y[k] = XA_S16(cy + d[k][1]);
+            x[k] = XA_S16(cx + tab<TAB>(first + k, 0));
+            y[k] = XA_S16(cy + tab<TAB>(first + k, 1));
         }
         W.template eval_points<N>(x, y, x, y, c);
 #pragma unroll
@@ -270,8 +293,8 @@ struct Search
 
     __device__ __forceinline__ void star_two_points(int bPointNr)
     {
-        const int x1 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2][0]), y1 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2][1]);
-        const int x2 = XA_S16(bmx + c_star_offsets[(bPointNr - 1) * 2 + 1][0]), y2 = XA_S16(bmy + c_star_offsets[(bPointNr - 1) * 2 + 1][1]);
+        const int x1 = XA_S16(bmx + tab<T_STAR>((bPointNr - 1) * 2, 0)), y1 = XA_S16(bmy + tab<T_STAR>((bPointNr - 1) * 2, 1));
+        const int x2 = XA_S16(bmx + tab<T_STAR>((bPointNr - 1) * 2 + 1, 0)), y2 = XA_S16(bmy + tab<T_STAR>((bPointNr - 1) * 2 + 1, 1));
         if (in_range(x1, y1)) try_mv(x1, y1);
         if (in_range(x2, y2)) try_mv(x2, y2);
     }
@@ -461,17 +484,17 @@ struct Search
         {
             ux = XA_S16(ux << 1);
             uy = XA_S16(uy << 1);
-            const int (*tab)[2] = pass ? c_refine_qpel : c_refine_hpel;
+            auto rt = [&](int i, int c) { return pass ? tab<T_REFINE_Q>(i, c) : tab<T_REFINE_H>(i, c); };
             const int scale = pass ? 1 : 2;
             int qx[8], qy[8], c[8];
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
-                qx[i] = XA_S16(XA_S16(ux + tab[i][0]) * scale);
-                qy[i] = XA_S16(XA_S16(uy + tab[i][1]) * scale);
+                qx[i] = XA_S16(XA_S16(ux + rt(i, 0)) * scale);
+                qy[i] = XA_S16(XA_S16(uy + rt(i, 1)) * scale);
             }
             W.subpel_cost8(8, qx, qy, X265AMD_SATD, c);
-            const int c8 = W.subpel_cost(XA_S16(XA_S16(ux + tab[8][0]) * scale), XA_S16(XA_S16(uy + tab[8][1]) * scale), X265AMD_SATD, true);
+            const int c8 = W.subpel_cost(XA_S16(XA_S16(ux + rt(8, 0)) * scale), XA_S16(XA_S16(uy + rt(8, 1)) * scale), X265AMD_SATD, true);
             int best = 0;
             bcost = c[0];
 #pragma unroll
@@ -486,8 +509,8 @@ struct Search
                 bcost = c8;
                 best = 8;
             }
-            ux = XA_S16(ux + tab[best][0]);
-            uy = XA_S16(uy + tab[best][1]);
+            ux = XA_S16(ux + rt(best, 0));
+            uy = XA_S16(uy + rt(best, 1));
         }
         outx = ux;
         outy = uy;
@@ -583,11 +606,11 @@ struct Search
             do
             {
                 const int cx = bmx, cy = bmy;
-                int k = probe<4>(cx, cy, &c_square1[1]);
+                int k = probe<4, T_SQUARE1>(cx, cy, 1);
                 if (k < 0)
                     break;
-                bmx = XA_S16(cx + c_square1[k + 1][0]);
-                bmy = XA_S16(cy + c_square1[k + 1][1]);
+                bmx = XA_S16(cx + tab<T_SQUARE1>(k + 1, 0));
+                bmy = XA_S16(cy + tab<T_SQUARE1>(k + 1, 1));
             }
             while (--i && in_range(bmx, bmy));
             break;
@@ -669,7 +692,7 @@ struct Search
                 }
                 int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
                 int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
-                merange = (merange * c_range_mul[mvd_ctx][sad_ctx]) >> 2;
+                merange = (merange * tab<T_RANGE_MUL>(mvd_ctx, sad_ctx)) >> 2;
             }
 #undef SAD_THRESH
             umh_cross(basex, basey, omx, omy, cross_start, merange, merange >> 1);
@@ -686,7 +709,7 @@ struct Search
                 {
                     for (int k = 0; k < 16; k++)
                     {
-                        int mx = XA_S16(omx + XA_S16(c_hex4[k][0] * i)), my = XA_S16(omy + XA_S16(c_hex4[k][1] * i));
+                        int mx = XA_S16(omx + XA_S16(tab<T_HEX4>(k, 0) * i)), my = XA_S16(omy + XA_S16(tab<T_HEX4>(k, 1) * i));
                         if (in_range(mx, my))
                             try_mv(mx, my);
                     }
@@ -702,8 +725,8 @@ struct Search
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                         {
-                            x[k] = omx + c_hex4[q * 4 + k][0] * i;
-                            y[k] = omy + c_hex4[q * 4 + k][1] * i;
+                            x[k] = omx + tab<T_HEX4>(q * 4 + k, 0) * i;
+                            y[k] = omy + tab<T_HEX4>(q * 4 + k, 1) * i;
                         }
                         W.template eval_points<4>(x, y, x, y, c, CF_NOTRUNC);
 #pragma unroll
@@ -718,8 +741,8 @@ struct Search
                     }
                     if (best >= 0)
                     {
-                        bmx = XA_S16(omx + i * c_hex4[best][0]);
-                        bmy = XA_S16(omy + i * c_hex4[best][1]);
+                        bmx = XA_S16(omx + i * tab<T_HEX4>(best, 0));
+                        bmy = XA_S16(omy + i * tab<T_HEX4>(best, 1));
                     }
                 }
                 i = XA_S16(i + 1);
@@ -785,24 +808,24 @@ struct Search
 
         if (do_hex)     // me_hex2 (motion.cpp:369-441)
         {
-            int dir = probe<6>(bmx, bmy, &c_hex2[1]);
+            int dir = probe<6, T_HEX2>(bmx, bmy, 1);
             if (dir >= 0)
             {
-                bmx = XA_S16(bmx + c_hex2[dir + 1][0]);
-                bmy = XA_S16(bmy + c_hex2[dir + 1][1]);
+                bmx = XA_S16(bmx + tab<T_HEX2>(dir + 1, 0));
+                bmy = XA_S16(bmy + tab<T_HEX2>(dir + 1, 1));
                 for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy); i--)
                 {
-                    int step = probe<3>(bmx, bmy, &c_hex2[dir]);
+                    int step = probe<3, T_HEX2>(bmx, bmy, dir);
                     if (step < 0)
                         break;
                     dir = (dir + step - 1 + 6) % 6;
-                    bmx = XA_S16(bmx + c_hex2[dir + 1][0]);
-                    bmy = XA_S16(bmy + c_hex2[dir + 1][1]);
+                    bmx = XA_S16(bmx + tab<T_HEX2>(dir + 1, 0));
+                    bmy = XA_S16(bmy + tab<T_HEX2>(dir + 1, 1));
                 }
             }
-            int sq = probe<8>(bmx, bmy, &c_square1[1]);
-            bmx = XA_S16(bmx + c_square1[sq + 1][0]);
-            bmy = XA_S16(bmy + c_square1[sq + 1][1]);
+            int sq = probe<8, T_SQUARE1>(bmx, bmy, 1);
+            bmx = XA_S16(bmx + tab<T_SQUARE1>(sq + 1, 0));
+            bmy = XA_S16(bmy + tab<T_SQUARE1>(sq + 1, 1));
         }
 
         W.stamp(4);
@@ -822,7 +845,8 @@ struct Search
         // sub-pel refinement (motion.cpp:786-861).  The reference's half-pel loop interpolates one
         // (w+1)xh or wx(h+1) block per direction pair; both members share the fractional phase,
         // so each candidate equals an independent subpelCompare.
-        const int *wl = c_workload[j.subme];
+        const int wl[5] = { tab<T_WORKLOAD>(j.subme, 0), tab<T_WORKLOAD>(j.subme, 1), tab<T_WORKLOAD>(j.subme, 2),
+                            tab<T_WORKLOAD>(j.subme, 3), tab<T_WORKLOAD>(j.subme, 4) };
         const int hkind = wl[4] ? X265AMD_SATD : W.ikind;
         if (wl[4])
             bcost = W.subpel_cost(bmx, bmy, X265AMD_SATD, true);
@@ -840,8 +864,8 @@ struct Search
             for (int it = 0; it < iters; it++)
             {
                 const int bdir = subpel_round(step, dirs, kind);
-                bmx = XA_S16(bmx + c_square1[bdir][0] * step);
-                bmy = XA_S16(bmy + c_square1[bdir][1] * step);
+                bmx = XA_S16(bmx + tab<T_SQUARE1>(bdir, 0) * step);
+                bmy = XA_S16(bmy + tab<T_SQUARE1>(bdir, 1) * step);
             }
         }
         W.stamp(5);
