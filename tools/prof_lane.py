@@ -30,9 +30,13 @@ def run(jobs, reps=3):
     return best
 
 print("X265AMD_FLAGS =", os.environ.get("X265AMD_FLAGS", "0"))
-for (w, h) in ((8, 8), (8, 4), (4, 8), (16, 4), (16, 8), (16, 16)):
+shapes = ((8, 8), (8, 4), (4, 8), (16, 4), (16, 8), (16, 16))
+if len(sys.argv) > 1 and sys.argv[1] == 'big':
+    shapes = ((8, 8), (16, 8), (16, 16), (32, 16), (32, 32))
+for (w, h) in shapes:
     x, y = J.square_pu_grid(W - (W % 16), H - (H % 16), max(w, h))
-    for (name, kw) in (("FULL+-16 subme0", dict(method=J.FULL, subme=0, merange=16)), ("HEX subme0", dict(method=J.HEX, subme=0, merange=64)),
+    kinds = (("FULL+-16 subme0", dict(method=J.FULL, subme=0, merange=16)), ("FULL+-16 subme5", dict(method=J.FULL, subme=5, merange=16))) if len(sys.argv) > 1 else None
+    for (name, kw) in kinds or (("FULL+-16 subme0", dict(method=J.FULL, subme=0, merange=16)), ("HEX subme0", dict(method=J.HEX, subme=0, merange=64)),
                        ("HEX subme5", dict(method=J.HEX, subme=5, merange=64)), ("STAR subme2", dict(method=J.STAR, subme=2, merange=32))):
         jobs = J.make_jobs(W, H, x, y, w, h, qp=32, **kw)
         eng.eval_count(reset=True)

@@ -75,8 +75,19 @@ constexpr int LANE_CLASS = 3;
 constexpr int LANE_MAX_AREA = 64;        // PU pixels of a quad-per-job search (four 4x4 tiles): 8x8, 8x4, 4x8, 16x4, 4x16, 4x4, 12x4, 4x12
 constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-out)
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
-// Is job (w, h) one for the quad-per-job kernel?  (`lane_on`: the batch's references are full-resolution planes)
-__device__ __host__ inline bool lane_job(int w, int h, bool lane_on) { return lane_on && w * h <= LANE_MAX_AREA; }
+constexpr int LANE_FULL_MAX_AREA = 64;   // ... and of a FULL job whose scan an exhaustive kernel ran (only a handful of evaluations are left of it).
+                                         // Measured on MI355X: beyond four tiles the quad's chain of tile steps (one memory round trip each) is longer
+                                         // than the general kernel's work - 16x16: 0.033 vs 0.026 ms per 1080p frame, 32x32: 0.095 vs 0.026 - so the
+                                         // default keeps those there (X265AMD_LANE_FULL raises it, up to 1024)
+// Is this job one for the quad-per-job kernel?  `lane_on`: 0 = no (a reference of the batch is a half-resolution set),
+// else the largest PU area it takes of FULL-search jobs whose scan ran in an exhaustive kernel (`covered`); any search
+// of a PU of at most LANE_MAX_AREA pixels goes there.
+template <class J>
+__device__ __host__ inline bool lane_job(const J &j, bool covered, int lane_on)
+{
+    const int area = j.w * j.h;
+    return lane_on && (area <= LANE_MAX_AREA || (covered && j.method == X265AMD_FULL && area <= lane_on));
+}
 
 template <class L>
 __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::NW == 1 && L::INL ? 8 : 1))) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,
@@ -99,8 +110,9 @@ __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::N
         }
         return;
     }
-    // (an index list names exactly this launch's jobs; without one every job is visited and the others are skipped)
-    if (!idx && (job_class(j.w, j.h) != cls || lane_job(j.w, j.h, P.lane_on != 0)))
+    const bool covered = fb && (P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(typename L::PIX)));
+    // (every launch visits its whole list - or every job, without one - and skips the jobs of the other classes)
+    if (job_class(j.w, j.h) != cls || (!idx && lane_job(j, covered, P.lane_on)))
         return;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
@@ -115,8 +127,7 @@ __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::N
     W.stamp(1);
     Search<L> S(W, j);
     int ox, oy;
-    const bool covered = P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(typename L::PIX));
-    const FullBest *f = (fb && covered) ? fb + (size_t)id * fb_stride : nullptr;
+    const FullBest *f = covered ? fb + (size_t)id * fb_stride : nullptr;
     int cost = S.run(f, fb_stride, ox, oy);
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     // (evaluation counts go to one of EVAL_SLOTS counters, 128 bytes apart, to spread the atomics)

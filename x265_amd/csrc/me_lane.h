@@ -72,12 +72,11 @@ struct QuadWave
     typedef Dev<JobLds<PIX, 1, 64>> D;
     static constexpr int DW = D::DW;
 
-    // per lane: the lane's tile of the job
-    const PIX *enc;                 // first pixel of the tile in the encoder plane
+    // the job, identical in the four lanes of its quad
+    const PIX *enc;                 // the PU's first pixel in the encoder plane
     const PIX *ref;                 // the reference pixel under it (encoder/motion.cpp:288)
     const uint16_t *cost;           // centre of the per-QP MV cost table
     int estride, stride, gLo, gHi;  // [gLo, gHi): element offsets relative to `ref` of the whole padded allocation
-    int on;                         // the PU has a tile for this lane (else the lane repeats tile 0 and adds nothing)
     int depth, w, h, mvpx, mvpy, ikind;
     unsigned evals;
     static constexpr bool lowres = false;
@@ -96,16 +95,13 @@ struct QuadWave
 
     __device__ __forceinline__ void bind(const PlaneDesc &e, const PlaneDesc &r, int pu_x, int pu_y, int w_, int h_, const uint16_t *cost_)
     {
-        const int t = (int)(threadIdx.x & 3), ntx = w_ >> 2;
-        on = t < ((w_ * h_) >> 4);
-        const int tx = on ? (t % ntx) * 4 : 0, ty = on ? (t / ntx) * 4 : 0;
-        enc = (const PIX*)e.origin + (int64_t)(pu_y + ty) * e.stride + pu_x + tx;
+        enc = (const PIX*)e.origin + (int64_t)pu_y * e.stride + pu_x;
         estride = e.stride;
-        const int64_t tileOffset = (int64_t)(pu_y + ty) * r.stride + pu_x + tx;
-        ref = (const PIX*)r.origin + tileOffset;
+        const int64_t blockOffset = (int64_t)pu_y * r.stride + pu_x;
+        ref = (const PIX*)r.origin + blockOffset;
         stride = r.stride;
-        gLo = (int32_t)(r.lo - tileOffset);
-        gHi = (int32_t)(r.hi - tileOffset);
+        gLo = (int32_t)(r.lo - blockOffset);
+        gHi = (int32_t)(r.hi - blockOffset);
         depth = DW == 1 ? 8 : r.depth;
         w = w_; h = h_;
         cost = cost_;
@@ -146,42 +142,100 @@ struct QuadWave
         return (cflags & CF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
     }
 
+    // The PU's 4x4 tiles are dealt to the quad's lanes in `tile_steps` steps of four tiles.  PUs whose sides are multiples
+    // of 8: step i is 8x8 block i, lane t takes its quadrant t (so the 8x8 transform's last stage stays inside the quad);
+    // sides multiples of 16: the blocks of one 16x16 block come in four consecutive steps (sa8d_inter rounds per 16x16
+    // there, common/pixel.cpp:347-362).  Any other PU: tile 4 i + t in raster order, `on` = the tile exists (a lane
+    // without one repeats tile 0 and adds nothing).
+    static __device__ __forceinline__ int tile_steps(int w, int h)
+    {
+        return ((w | h) & 7) ? (((w * h) >> 4) + 3) >> 2 : (w * h) >> 6;
+    }
+    static __device__ __forceinline__ void tile_at(int i, int w, int h, int &tx, int &ty, bool &on)
+    {
+        const int t = (int)(threadIdx.x & 3);
+        if (((w | h) & 7) == 0)
+        {
+            int bx, by;
+            if (((w | h) & 15) == 0)
+            {
+                const int g = i >> 2, q = i & 3, ngx = w >> 4, gy = g / ngx, gx = g - gy * ngx;
+                bx = gx * 2 + (q & 1);
+                by = gy * 2 + (q >> 1);
+            }
+            else
+            {
+                const int nbx = w >> 3;
+                by = i / nbx;
+                bx = i - by * nbx;
+            }
+            tx = bx * 8 + (t & 1) * 4;
+            ty = by * 8 + (t >> 1) * 4;
+            on = true;
+        }
+        else
+        {
+            const int ntx = w >> 2, tt = 4 * i + t;
+            on = tt < ((w * h) >> 4);
+            const int u = on ? tt : 0;
+            ty = u / ntx;
+            tx = (u - ty * ntx) * 4;
+            ty *= 4;
+        }
+    }
+
     // ---------------------------------------------------------------- full-pel SADs of up to NB candidates in one call
     // pos[k] = (y << 16) | (x & 0xffff): full-pel position measured; lbl[k]: q-pel label priced.  Entries >= n repeat
     // entry 0 (their loads hit the same lines; their costs are not used).  All loads are issued before the first use.
     template <int NB>
-    static __device__ __noinline__ P8 sad_multi(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi, int on,
+    static __device__ __noinline__ P8 sad_multi(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi, int wh,
                                                 const uint16_t *cost, int mvp, int cflags, P8 pos, P8 lbl)
     {
-        uint32_t e[4][2], r[NB][4][2];
-        int mv[NB];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            rd4(enc + i * estride, e[i]);
+        const int w = wh & 0xff, h = wh >> 8, steps = tile_steps(w, h);
+        int mv[NB], off[NB];
+        uint32_t s[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++)
         {
-            const int off = (pos[k] >> 16) * stride + (int)(int16_t)pos[k];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                rd4(ref + clamp_off(off + i * stride, 4, gLo, gHi), r[k][i]);
+            off[k] = (pos[k] >> 16) * stride + (int)(int16_t)pos[k];
             mv[k] = (cflags & CF_NOMV) ? 0 : mv_cost(cost, mvp, lbl[k], cflags);
+            s[k] = 0;
+        }
+        for (int i = 0; i < steps; i++)
+        {
+            int tx, ty;
+            bool on;
+            tile_at(i, w, h, tx, ty, on);
+            const PIX *et = enc + ty * estride + tx;
+            const int toff = ty * stride + tx;
+            uint32_t e[4][2], r[NB][4][2];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                rd4(et + y * estride, e[y]);
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    rd4(ref + clamp_off(off[k] + toff + y * stride, 4, gLo, gHi), r[k][y]);
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+            {
+                uint32_t a = 0;
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                {
+                    if (DW == 1)
+                        a = __builtin_amdgcn_sad_u8(e[y][0], r[k][y][0], a);
+                    else
+                        a = __builtin_amdgcn_sad_u16(e[y][1], r[k][y][1], __builtin_amdgcn_sad_u16(e[y][0], r[k][y][0], a));
+                }
+                s[k] += on ? a : 0;
+            }
         }
         P8 out = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
         for (int k = 0; k < NB; k++)
-        {
-            uint32_t s = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                if (DW == 1)
-                    s = __builtin_amdgcn_sad_u8(e[i][0], r[k][i][0], s);
-                else
-                    s = __builtin_amdgcn_sad_u16(e[i][1], r[k][i][1], __builtin_amdgcn_sad_u16(e[i][0], r[k][i][0], s));
-            }
-            out[k] = quad_sum(on ? (int)s : 0) + mv[k];
-        }
+            out[k] = quad_sum((int)s[k]) + mv[k];
         return out;
     }
 
@@ -205,129 +259,143 @@ struct QuadWave
 
     // Cost of kind `kind` of the PU against the candidate at q-pel (qx, qy) (subpelCompare, encoder/motion.cpp:1140-1165;
     // at a full-pel position the plain primitive) plus, unless CF_NOMV, the MV cost of the q-pel label.
-    static __device__ __noinline__ int cost_one(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi, int on,
+    static __device__ __noinline__ int cost_one(const PIX *enc, int estride, const PIX *ref, int stride, int gLo, int gHi,
                                                 int dwh, const uint16_t *cost, int mvp, int qx, int qy, int label, int kf)
     {
         const int depth = dwh & 0xff, w = (dwh >> 8) & 0xff, h = dwh >> 16;
         const int kind = kf & 3, cflags = kf >> 2;
         const int xf = qx & 3, yf = qy & 3;
-        const int off = (qy >> 2) * stride + (qx >> 2);
+        const int off0 = (qy >> 2) * stride + (qx >> 2);
         const int mv = (cflags & CF_NOMV) ? 0 : mv_cost(cost, mvp, label, cflags);
-        uint32_t e[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            rd4(enc + i * estride, e[i]);
-        // the lane's 4x4 tile of the prediction block
-        int p[4][4];
-        if (!xf && !yf)
+        const int am = D::accum_mode(kind, w, h), steps = tile_steps(w, h);
+        int acc = 0, tot = 0;                   // acc: magnitudes not yet rounded (am 3: of the running 16x16 block)
+        for (int i = 0; i < steps; i++)
         {
+            int tx, ty;
+            bool on;
+            tile_at(i, w, h, tx, ty, on);
+            const PIX *et = enc + ty * estride + tx;
+            const int off = off0 + ty * stride + tx;
+            uint32_t e[4][2];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int y = 0; y < 4; y++)
+                rd4(et + y * estride, e[y]);
+            // the lane's 4x4 tile of the prediction block
+            int p[4][4];
+            if (!xf && !yf)
             {
-                uint32_t d[2];
-                rd4(ref + clamp_off(off + i * stride, 4, gLo, gHi), d);
-                const P4 v = D::unpack4(d);
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    p[i][c] = v.v[c];
-            }
-        }
-        else if (!yf)           // filterHorizontal_p_p
-        {
-            uint32_t px[4][6];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                const PIX *q = ref + clamp_off(off + i * stride - 3, 12, gLo, gHi);
-#pragma unroll
-                for (int k = 0; k < 3 * DW; k++)
-                    px[i][k] = ld_u32((const uint8_t*)q + 4 * k);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                D::h_pp(px[i], xf, depth, p[i]);
-        }
-        else if (!xf)           // filterVertical_p_p
-        {
-            uint32_t rw[11][2];
-#pragma unroll
-            for (int k = 0; k < 11; k++)
-            {
-                rw[k][1] = 0;
-                rd4(ref + clamp_off(off + (k - 3) * stride, 4, gLo, gHi), rw[k]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                D::v_pp(rw + i, yf, depth, p[i]);
-        }
-        else                    // filterHorizontal_p_s over rows -3 .. 7, then filterVertical_s_p
-        {
-            uint32_t px[11][6], im[11][2];
-#pragma unroll
-            for (int k = 0; k < 11; k++)
-            {
-                const PIX *q = ref + clamp_off(off + (k - 3) * stride - 3, 12, gLo, gHi);
-#pragma unroll
-                for (int i = 0; i < 3 * DW; i++)
-                    px[k][i] = ld_u32((const uint8_t*)q + 4 * i);
-            }
-#pragma unroll
-            for (int k = 0; k < 11; k++)
-            {
-                int sm[4];
-                D::h_ps(px[k], xf, depth, sm);
-                im[k][0] = __builtin_amdgcn_perm((uint32_t)sm[1], (uint32_t)sm[0], 0x05040100);
-                im[k][1] = __builtin_amdgcn_perm((uint32_t)sm[3], (uint32_t)sm[2], 0x05040100);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                D::v_sp(im + i, yf, depth, p[i]);
-        }
-        int d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            const P4 f = D::unpack4(e[i]);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                d[i][c] = on ? f.v[c] - p[i][c] : 0;
-        }
-        const int am = D::accum_mode(kind, w, h);
-        if (am >= 1)
-            had4(d);
-        if (am >= 2)
-        {
-            // the 8x8 transform = the four tiles' 4x4 transforms and one butterfly across the quad per direction
-            const bool hx = (threadIdx.x & 1) != 0, hy = (threadIdx.x & 2) != 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
+                for (int y = 0; y < 4; y++)
                 {
-                    int v = d[i][c];
-                    const int px = dpp<0xB1>(v);
-                    v = hx ? px - v : v + px;
-                    const int py = dpp<0x4E>(v);
-                    d[i][c] = hy ? py - v : v + py;
+                    uint32_t d[2];
+                    rd4(ref + clamp_off(off + y * stride, 4, gLo, gHi), d);
+                    const P4 v = D::unpack4(d);
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        p[y][c] = v.v[c];
                 }
+            }
+            else if (!yf)           // filterHorizontal_p_p
+            {
+                uint32_t px[4][6];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                {
+                    const PIX *q = ref + clamp_off(off + y * stride - 3, 12, gLo, gHi);
+#pragma unroll
+                    for (int k = 0; k < 3 * DW; k++)
+                        px[y][k] = ld_u32((const uint8_t*)q + 4 * k);
+                }
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    D::h_pp(px[y], xf, depth, p[y]);
+            }
+            else if (!xf)           // filterVertical_p_p
+            {
+                uint32_t rw[11][2];
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+                {
+                    rw[k][1] = 0;
+                    rd4(ref + clamp_off(off + (k - 3) * stride, 4, gLo, gHi), rw[k]);
+                }
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    D::v_pp(rw + y, yf, depth, p[y]);
+            }
+            else                    // filterHorizontal_p_s over rows -3 .. 7, then filterVertical_s_p
+            {
+                uint32_t px[11][6], im[11][2];
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+                {
+                    const PIX *q = ref + clamp_off(off + (k - 3) * stride - 3, 12, gLo, gHi);
+#pragma unroll
+                    for (int c = 0; c < 3 * DW; c++)
+                        px[k][c] = ld_u32((const uint8_t*)q + 4 * c);
+                }
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+                {
+                    int sm[4];
+                    D::h_ps(px[k], xf, depth, sm);
+                    im[k][0] = __builtin_amdgcn_perm((uint32_t)sm[1], (uint32_t)sm[0], 0x05040100);
+                    im[k][1] = __builtin_amdgcn_perm((uint32_t)sm[3], (uint32_t)sm[2], 0x05040100);
+                }
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    D::v_sp(im + y, yf, depth, p[y]);
+            }
+            int d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                const P4 f = D::unpack4(e[y]);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    d[y][c] = on ? f.v[c] - p[y][c] : 0;
+            }
+            if (am >= 1)
+                had4(d);
+            if (am >= 2)
+            {
+                // the 8x8 transform = the four tiles' 4x4 transforms and one butterfly across the quad per direction
+                const bool hx = (threadIdx.x & 1) != 0, hy = (threadIdx.x & 2) != 0;
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                    {
+                        int v = d[y][c];
+                        const int px = dpp<0xB1>(v);
+                        v = hx ? px - v : v + px;
+                        const int py = dpp<0x4E>(v);
+                        d[y][c] = hy ? py - v : v + py;
+                    }
+            }
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    acc += d[y][c] < 0 ? -d[y][c] : d[y][c];
+            if (am == 2 || (am == 3 && (i & 3) == 3))
+            {
+                tot += (quad_sum(acc) + 2) >> 2;            // sa8d8 rounds per 8x8, sa8d16 per 16x16
+                acc = 0;
+            }
         }
-        int s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                s += d[i][c] < 0 ? -d[i][c] : d[i][c];
-        s = quad_sum(s);
-        if (am == 1)
-            s >>= 1;                            // every 4x4 sum of magnitudes is even
-        else if (am >= 2)
-            s = (s + 2) >> 2;                   // sa8d_8x8 (this class has no PU of 16x16 and more)
-        return s + mv;
+        if (am <= 1)
+        {
+            tot = quad_sum(acc);
+            if (am == 1)
+                tot >>= 1;                                  // every 4x4 sum of magnitudes is even
+        }
+        return tot + mv;
     }
 
     __device__ __forceinline__ int cost_at(int qx, int qy, int lx, int ly, int kind, int cflags) const
     {
-        return cost_one(enc, estride, ref, stride, gLo, gHi, on, depth | (w << 8) | (h << 16), cost,
+        return cost_one(enc, estride, ref, stride, gLo, gHi, depth | (w << 8) | (h << 16), cost,
                         (mvpx & 0xffff) | (mvpy << 16), qx, qy, (lx & 0xffff) | (ly << 16), kind | (cflags << 2));
     }
 
@@ -348,7 +416,7 @@ struct QuadWave
                 pos[k] = (sy[s] << 16) | (sx[s] & 0xffff);
                 lbl[k] = ((int)(int16_t)((int16_t)ly[s] << sh) << 16) | ((int)(int16_t)((int16_t)lx[s] << sh) & 0xffff);
             }
-            const P8 c = sad_multi<NB>(enc, estride, ref, stride, gLo, gHi, on, cost, (mvpx & 0xffff) | (mvpy << 16), pflags, pos, lbl);
+            const P8 c = sad_multi<NB>(enc, estride, ref, stride, gLo, gHi, w | (h << 8), cost, (mvpx & 0xffff) | (mvpy << 16), pflags, pos, lbl);
 #pragma unroll
             for (int k = 0; k < N; k++)
                 out[k] = c[k];
@@ -452,7 +520,8 @@ __global__ void __launch_bounds__(64) k_lane(BatchParams P, const x265amd_me_job
         JobRegs j;
         j.load(jobs + id);
         const bool valid = idx || job_fields_valid(j, P.n_refs);
-        if (valid && lane_job(j.w, j.h, true))
+        const bool covered = fb && (P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(PIX)));
+        if (valid && (idx || lane_job(j, covered, P.lane_on)))
         {
             const PlaneDesc &enc = P.planes[P.enc_plane];
             const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
@@ -460,8 +529,7 @@ __global__ void __launch_bounds__(64) k_lane(BatchParams P, const x265amd_me_job
             W.bind(enc, ref, j.pu_x, j.pu_y, j.w, j.h, P.cost[j.qp]);
             Search<LaneCfg, QuadWave<PIX>> S(W, j);
             int ox, oy;
-            const bool covered = P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(PIX));
-            const FullBest *f = (fb && covered) ? fb + (size_t)id * fb_stride : nullptr;
+            const FullBest *f = covered ? fb + (size_t)id * fb_stride : nullptr;
             const int cost = S.run(f, fb_stride, ox, oy);
             if ((threadIdx.x & 3) == 0)
             {

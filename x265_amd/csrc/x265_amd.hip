@@ -77,6 +77,7 @@ struct x265amd_ctx
     DevBuf field_results, field_mvp;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
+    int    lane_full_area = LANE_FULL_MAX_AREA;   // largest PU of a FULL job with an exhaustive-kernel scan that the quad-per-job kernel takes
     bool   hier_ok = false;               // the MV-cost tables are small enough for the hierarchical kernel's 32-bit keys
     bool   timing = false;
     int    flags = 0;
@@ -323,8 +324,15 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
         hipLaunchKernelGGL(k_lane<PIX>, dim3((cnt[LANE_CLASS] + 15) / 16), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[LANE_CLASS], cnt[LANE_CLASS],
                            fb, fb_stride, d_out, c->d_evals);
     else if (cnt[LANE_CLASS] > 0 && idx[LANE_CLASS])
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[LANE_CLASS]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[LANE_CLASS],
-                           cnt[LANE_CLASS], 0, fb, fb_stride, d_out, c->d_evals);
+    {
+        // (a planned list run against half-resolution references: its quad-per-job class goes through the general kernel,
+        // every launch taking the jobs of its own class)
+        hipStream_t st = c->lane(side_by_side ? k++ : 0);
+        const int m = cnt[LANE_CLASS];
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 1024, LR, !LR>>), dim3(m), dim3(256), 0, st, P, d_jobs, idx[LANE_CLASS], m, 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[LANE_CLASS], m, 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[LANE_CLASS], m, 0, fb, fb_stride, d_out, c->d_evals);
+    }
 }
 
 int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd_me_job *d_jobs, int n,
@@ -353,7 +361,7 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
     bool lr = false;
     for (int i = 0; i < P.n_refs; i++)
         lr = lr || c->h_planes[P.ref_planes[i]].lr_step != 0;
-    P.lane_on = !lr && !(c->flags & 128);       // (tuning aid: X265AMD_FLAGS bit 7 keeps the smallest PUs in the general kernel)
+    P.lane_on = (!lr && !(c->flags & 128)) ? c->lane_full_area : 0;       // (tuning aid: X265AMD_FLAGS bit 7 keeps every PU in the general kernel)
     if (bpp == 1 && !lr)
         launch_classes<uint8_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else if (bpp == 1)
@@ -824,58 +832,6 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     if (int rc = ensure(c, L->results, (size_t)n * sizeof(x265amd_me_result))) return rc;
     HIPCHK(c, hipMemcpyAsync(L->jobs.p, jobs, (size_t)n * sizeof(x265amd_me_job), hipMemcpyHostToDevice, c->stream));
 
-    {
-        std::vector<int> order;
-        for (int cls = 0; cls < JOB_CLASSES; cls++)
-        {
-            std::vector<int> seg;
-            for (int i = 0; i < n; i++)
-                if ((lane_job(jobs[i].w, jobs[i].h, true) ? LANE_CLASS : job_class(jobs[i].w, jobs[i].h)) == cls)
-                    seg.push_back(i);
-            L->cls_count[cls] = (int)seg.size();
-            if (!(c->flags & 8))        // (tuning aid: X265AMD_FLAGS bit 3 keeps the caller's job order)
-            {
-                if (cls == LANE_CLASS)
-                {
-                    // one job per quad of lanes: a wavefront takes 16 consecutive entries.  Jobs of one shape and search kind
-                    // together (the quads of a wavefront then run the same loops), each group in picture order (their
-                    // row reads share cache lines); whole wavefronts are dealt to the XCDs
-                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
-                        const x265amd_me_job &x = jobs[a], &y = jobs[b];
-                        return std::make_tuple((int)x.ref_idx, (int)x.method, (int)x.subme, (int)x.w, (int)x.h, x.pu_y, x.pu_x) <
-                               std::make_tuple((int)y.ref_idx, (int)y.method, (int)y.subme, (int)y.w, (int)y.h, y.pu_y, y.pu_x); });
-                    std::vector<std::vector<int>> chunks;
-                    for (size_t a = 0; a < seg.size(); a += 16)
-                        chunks.emplace_back(seg.begin() + a, seg.begin() + std::min(seg.size(), a + 16));
-                    // (only whole chunks may move: the last, partial one stays last)
-                    std::vector<std::vector<int>> whole(chunks.begin(), chunks.end() - (chunks.empty() || chunks.back().size() == 16 ? 0 : 1));
-                    xcd_interleave(whole);
-                    std::vector<int> flat;
-                    for (auto &ch : whole)
-                        flat.insert(flat.end(), ch.begin(), ch.end());
-                    if (!chunks.empty() && chunks.back().size() != 16)
-                        flat.insert(flat.end(), chunks.back().begin(), chunks.back().end());
-                    seg.swap(flat);
-                }
-                else
-                {
-                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
-                        return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
-                               std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
-                    xcd_interleave(seg);
-                }
-            }
-            order.insert(order.end(), seg.begin(), seg.end());
-        }
-        if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
-        L->order.swap(order);           // (the list keeps the host copy: it outlives the asynchronous upload)
-        HIPCHK(c, hipMemcpyAsync(L->idx.p, L->order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        if (L->keep_hist)
-        {
-            if (int rc = ensure(c, L->hist, (size_t)n * sizeof(unsigned))) return rc;
-            HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
-        }
-    }
     std::vector<char> in_bundle(n, 0);
     std::vector<HierBundle> hbundles;
     std::vector<HierItem> hitems;
@@ -935,6 +891,60 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         if (int rc = ensure(c, L->hier_fenc, hbundles.size() * (size_t)HIER_FENC_DW * 4)) return rc;
         HIPCHK(c, hipMemcpyAsync(L->hier_bundles.p, hbundles.data(), hbundles.size() * sizeof(HierBundle), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L->hier_items.p, hitems.data(), hitems.size() * sizeof(HierItem), hipMemcpyHostToDevice, c->stream));
+    }
+    // job classes and launch order (after the bundles are known: a FULL job whose scan an exhaustive kernel runs leaves
+    // only a handful of evaluations to the search kernels)
+    {
+        std::vector<int> order;
+        for (int cls = 0; cls < JOB_CLASSES; cls++)
+        {
+            std::vector<int> seg;
+            for (int i = 0; i < n; i++)
+                if ((lane_job(jobs[i], full_kernel_eligible(jobs[i], bpp) || in_bundle[i], (c->flags & 128) ? 0 : c->lane_full_area) ? LANE_CLASS : job_class(jobs[i].w, jobs[i].h)) == cls)
+                    seg.push_back(i);
+            L->cls_count[cls] = (int)seg.size();
+            if (!(c->flags & 8))        // (tuning aid: X265AMD_FLAGS bit 3 keeps the caller's job order)
+            {
+                if (cls == LANE_CLASS)
+                {
+                    // one job per quad of lanes: a wavefront takes 16 consecutive entries.  Jobs of one shape and search kind
+                    // together (the quads of a wavefront then run the same loops), each group in picture order (their
+                    // row reads share cache lines); whole wavefronts are dealt to the XCDs
+                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                        const x265amd_me_job &x = jobs[a], &y = jobs[b];
+                        return std::make_tuple((int)x.ref_idx, (int)x.method, (int)x.subme, (int)x.w, (int)x.h, x.pu_y, x.pu_x) <
+                               std::make_tuple((int)y.ref_idx, (int)y.method, (int)y.subme, (int)y.w, (int)y.h, y.pu_y, y.pu_x); });
+                    std::vector<std::vector<int>> chunks;
+                    for (size_t a = 0; a < seg.size(); a += 16)
+                        chunks.emplace_back(seg.begin() + a, seg.begin() + std::min(seg.size(), a + 16));
+                    // (only whole chunks may move: the last, partial one stays last)
+                    std::vector<std::vector<int>> whole(chunks.begin(), chunks.end() - (chunks.empty() || chunks.back().size() == 16 ? 0 : 1));
+                    xcd_interleave(whole);
+                    std::vector<int> flat;
+                    for (auto &ch : whole)
+                        flat.insert(flat.end(), ch.begin(), ch.end());
+                    if (!chunks.empty() && chunks.back().size() != 16)
+                        flat.insert(flat.end(), chunks.back().begin(), chunks.back().end());
+                    seg.swap(flat);
+                }
+                else
+                {
+                    std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
+                        return std::make_tuple((int)jobs[a].ref_idx, jobs[a].pu_y, jobs[a].pu_x) <
+                               std::make_tuple((int)jobs[b].ref_idx, jobs[b].pu_y, jobs[b].pu_x); });
+                    xcd_interleave(seg);
+                }
+            }
+            order.insert(order.end(), seg.begin(), seg.end());
+        }
+        if (int rc = ensure(c, L->idx, (size_t)n * sizeof(int))) return rc;
+        L->order.swap(order);           // (the list keeps the host copy: it outlives the asynchronous upload)
+        HIPCHK(c, hipMemcpyAsync(L->idx.p, L->order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (L->keep_hist)
+        {
+            if (int rc = ensure(c, L->hist, (size_t)n * sizeof(unsigned))) return rc;
+            HIPCHK(c, hipMemsetAsync(L->hist.p, 0, (size_t)n * sizeof(unsigned), c->stream));
+        }
     }
     std::vector<PlannedItem> planned;
     {
@@ -1264,6 +1274,8 @@ int x265amd_create(int device, x265amd_ctx **out)
         c->flags = atoi(ev);
         g_no_xcd_bands = (c->flags & 4) != 0;
     }
+    if (const char *ev = getenv("X265AMD_LANE_FULL"))    // tuning aid: see lane_full_area (at least LANE_MAX_AREA)
+        c->lane_full_area = std::max(LANE_MAX_AREA, std::min(4096, atoi(ev)));
     if (const char *ev = getenv("X265AMD_LANES"))        // streams the independent kernels of a batch are spread over
         c->n_lanes = std::max(1, std::min(x265amd_ctx::N_AUX + 1, atoi(ev)));
     if ((e = resolve_scratch(device)) != hipSuccess)
