@@ -63,7 +63,9 @@ def cpu_baseline(budget_s=6.0):
     have = {k: os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libx265ref%s.so" % k)) for k in ("8", "8v")}
     if not have["8"]:
         return None
-    cores = min(16, os.cpu_count() or 1)
+    # the job's share of the host: a one-GPU box grants 16 cores of a much larger machine (OMP_NUM_THREADS says how many)
+    host_cpus = os.cpu_count() or 1
+    cores = max(1, min(host_cpus, int(os.environ.get("X265AMD_BENCH_CORES", os.environ.get("OMP_NUM_THREADS", "16")))))
     env = dict(os.environ, OMP_NUM_THREADS="8")
 
     def run(kind, leg, procs, seconds, evals=None):
@@ -89,8 +91,9 @@ def cpu_baseline(budget_s=6.0):
                                      "pixel_sads_per_s": v1["pixel_sads"] / v1["seconds"] if leg == "full" else None}
             vn = run("8v", leg, cores, budget_s / 2, per_pass)
             out[leg]["vec_all_cores"] = {"value": sum(o["evals"] for o in vn) / max(o["seconds"] for o in vn), "unit": "evals/s",
-                                         "cores": cores, "kind": "reference",
-                                         "path": "intrinsic primitives, one process (one MotionEstimate) per core, each on the same sample"}
+                                         "cores": cores, "host_cpus": host_cpus, "kind": "reference",
+                                         "path": "intrinsic primitives, one process (one MotionEstimate) per core, each on the same sample; "
+                                                 "%d of the machine's %d CPUs (the share this job may use)" % (cores, host_cpus)}
     return out
 
 
@@ -146,9 +149,13 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("X265AMD_BENCH_TRACE_AFTER", "90")), exit=False)
     trace("process group up")
-    from x265_amd.api import Engine
+    from x265_amd.api import Engine, build_info
+    from x265_amd import build as xbuild
     eng = Engine(local_rank)
     trace("engine created")
+    # which sources the loaded binary was built from, and whether the tree beside it still holds those sources
+    library_id = {"build_info": build_info(), "tree_source_hash": xbuild.source_hash(),
+                  "binary_matches_tree": build_info().endswith(xbuild.source_hash())}
 
     # ---- inputs, resident in HBM ---------------------------------------------------------
     base = synth.base_frame(W, H)
@@ -243,6 +250,9 @@ def main():
         except Exception:
             return None
 
+    TRAFFIC_SOURCE = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/final_profiles.sh) over this "
+                      "command on the committed state; read from that file, not measured in this run")
+
     prop = torch.cuda.get_device_properties(local_rank)
     cus = prop.multi_processor_count
     clk_hz = prop.clock_rate * 1e3 if hasattr(prop, "clock_rate") else 2.4e9
@@ -262,23 +272,26 @@ def main():
         full = {
             "value": fevals / fdt, "ms_per_step": fdt / args.steps * 1e3, "frames_per_s": world * args.steps / fdt,
             "evals_per_frame": fevals / (args.steps * world),
-            "roofline": {"bound": "valu", "kernel": "k_full_hier", "achieved": px_alg / (k_full_ms * 1e-3) / 1e12, "peak": sad_peak / 1e12,
-                         "unit": "T pixel-SAD/s", "frac": px_alg / (k_full_ms * 1e-3) / sad_peak,
-                         "traffic": pmc("k_full_hier_bytes_per_launch"),
+            "roofline": {"bound": "valu", "kernel": "k_full_hier", "achieved": px_exec / (k_full_ms * 1e-3) / 1e12, "peak": sad_peak / 1e12,
+                         "unit": "T pixel-SAD/s", "frac": px_exec / (k_full_ms * 1e-3) / sad_peak,
+                         "algorithmic_achieved": px_alg / (k_full_ms * 1e-3) / 1e12,
+                         "algorithmic_frac": px_alg / (k_full_ms * 1e-3) / sad_peak,
+                         "traffic": pmc("k_full_hier_bytes_per_launch"), "traffic_source": TRAFFIC_SOURCE,
                          "kernel_ms": k_full_ms, "search_kernel_ms": k_tail_ms,
                          "kernel_ms_is": "HIP-event bracket on the engine's stream around the exhaustive kernels (k_pack_fenc + k_full_hier) "
-                                         "of the last step of the timed region; search_kernel_ms: the same around the general kernel "
+                                         "of the last step of the timed region; search_kernel_ms: the same around the search kernels "
                                          "(predictors, slab combine, half-pel SAD round, final SATD)",
                          "algorithmic_pixel_sads_per_launch": px_alg,
                          "executed_pixel_sads_per_launch": px_exec,
-                         "executed_frac": px_exec / (k_full_ms * 1e-3) / sad_peak,
-                         "note": "achieved / frac use the ALGORITHMIC work (every PU's candidates x its own pixels, 1.35e11 per frame); the kernel "
-                                 "measures only the 8x8 cells and sums them up the quadtree (executed = a quarter), so frac can exceed 1; "
-                                 "executed_frac is the instruction-level utilisation of the packed-SAD pipe",
+                         "note": "achieved / frac count the pixel-SADs the kernel EXECUTES (the 8x8 cells of every candidate, 3.4e10 per frame): "
+                                 "the utilisation of the packed-SAD pipe, at most 1. algorithmic_* count every PU's candidates x its own pixels "
+                                 "(1.35e11 per frame, the survey's definition of work): the kernel sums the cells up the quadtree instead of "
+                                 "measuring each level, so that ratio exceeds 1",
                          "peak_def": "%d CUs x %d lanes/clk x 4 px (v_sad_u8 / v_qsad_pk_u16_u8) x %.2f GHz" % (cus, SAD_LANES_PER_CLK_PER_CU, clk_hz / 1e9)},
             "roofline_hbm": {"bound": "hbm", "kernel": "k_full_hier", "achieved": full_bytes / (k_full_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": full_bytes / (k_full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": full_bytes, "traffic": pmc("k_full_hier_bytes_per_launch")},
+                             "algorithmic_bytes_per_launch": full_bytes, "traffic": pmc("k_full_hier_bytes_per_launch"),
+                             "traffic_source": TRAFFIC_SOURCE},
         }
     if run_hex:
         hdt, hevals, _, k_hex_ms = timed(jl_hex, args.warmup, args.steps)
@@ -311,7 +324,8 @@ def main():
                          "ops_def": "SAD evaluation = w*h, SATD evaluation = 5*w*h integer operations"},
             "roofline_hbm": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": hex_bytes / (k_hex_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hex_bytes / (k_hex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": hex_bytes, "traffic": pmc("k_search_u8_bytes_per_launch")},
+                             "algorithmic_bytes_per_launch": hex_bytes, "traffic": pmc("k_search_u8_bytes_per_launch"),
+                             "traffic_source": TRAFFIC_SOURCE},
         }
 
     # ---- the exchange step alone (N > 1): reference plane from rank 0 to every rank ----------------
@@ -356,6 +370,7 @@ def main():
         "roofline": full["roofline"],
         "roofline_hbm": full["roofline_hbm"],
         "cpu_baseline": None,
+        "library": library_id,
     }
 
     # With N > 1 only the leg `value` is quoted on runs (plus the broadcast alone): the secondary legs are
@@ -403,6 +418,49 @@ def main():
         pcie[name] = {"ms_per_frame": d / args.steps * 1e3, "frames_per_s": args.steps / d, "value": ev * args.steps / d, "unit": "evals/s"}
     line["pcie_inclusive"] = {"workload": "enc and ref planes copied host->device and the MV/cost field device->host every frame, "
                                           "frames not overlapped", **pcie}
+
+    # The same with the frames pipelined (SURVEY 8(d)'s wall-clock including H2D and D2H): two sets of planes; the planes of frame
+    # k + 1 are refilled through the library (x265amd_plane_refill_async: behind the searches queued so far, beside the search of
+    # frame k) and the field of frame k comes down behind its search (x265amd_joblist_results_async into page-locked memory);
+    # the host waits once at the end
+    sets = [{"enc_id": eng.upload_plane(enc_np), "ref_id": eng.upload_plane(ref_np)} for _ in range(2)]
+    piped = {}
+    for name, jobs_np, ev in (("full_search", full_jobs, full["evals_per_frame"]), ("hex_search", hex_jobs, hexr["evals_per_frame"])):
+        jls = [eng.make_joblist(jobs_np) for _ in range(2)]
+        outs = [torch.zeros(len(jobs_np) * 8, dtype=torch.uint8).pin_memory() for _ in range(2)]
+
+        def frame(k):
+            nxt = sets[(k + 1) & 1]
+            eng.refill_plane_async(nxt["enc_id"], enc_pin.data_ptr())
+            eng.refill_plane_async(nxt["ref_id"], ref_pin.data_ptr())
+            st = sets[k & 1]
+            jls[k & 1].run(st["enc_id"], [st["ref_id"]], fetch=False)
+            jls[k & 1].results_async(outs[k & 1].data_ptr())
+
+        for k in range(4):
+            frame(k)
+        eng.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            frame(k)
+        eng.sync()
+        barrier()
+        d = time.perf_counter() - t0
+        got = outs[(args.steps - 1) & 1].numpy().view(J.RESULT_DTYPE)
+        same = bool(np.array_equal(got, full_res if name == "full_search" else hex_res))
+        piped[name] = {"ms_per_frame": d / args.steps * 1e3, "frames_per_s": args.steps / d, "value": ev * args.steps / d, "unit": "evals/s",
+                       "field_equals_resident_run": same}
+        for j in jls:
+            j.close()
+    for st in sets:
+        eng.release_plane(st["enc_id"])
+        eng.release_plane(st["ref_id"])
+    line["pcie_inclusive"]["pipelined"] = {"workload": "the same traffic with the frames pipelined: planes of frame k + 1 uploaded beside the search of "
+                                                       "frame k (two plane sets, x265amd_plane_refill_async), field of frame k downloaded behind its search "
+                                                       "into page-locked memory (x265amd_joblist_results_async); the host waits once at the end",
+                                           **piped, "vs_resident": piped["full_search"]["ms_per_frame"] / full["ms_per_step"]}
+    ok_pipe = all(v["field_equals_resident_run"] for v in piped.values())
 
     # ---- lookahead path (not part of `value`): half-resolution plane sets and whole-frame
     # neighbour-predicted searches with the reference's lookahead settings (HEX, subme 1, merange 16, qp 12)
@@ -452,16 +510,21 @@ def main():
     had_res = jl_had.results()
     jl_had.close()
     had_ops = float(sum(7.0 * s * s * J.full_search_evals(had_jobs[had_jobs["w"] == s]) for s in (64, 32, 16, 8)))
+    had_exec = float(7.0 * 64 * J.full_search_evals(had_jobs[had_jobs["w"] == 8]))
     line["sa8d_full_4k10"] = {"workload": "4K 10-bit synthetic, exhaustive +-16 integer search with the SA8D metric of every square PU "
                                           "64/32/16/8, subme 0 (BASELINE configs[4]'s metric and pixel type)",
                               "jobs_per_frame": int(len(had_jobs)), "evals_per_frame": had_evals, "value": had_evals / had_dt,
                               "unit": "evals/s", "ms_per_frame": had_dt * 1e3,
-                              "roofline": {"bound": "valu", "kernel": "k_full_had<uint16_t>", "achieved": had_ops / (k_had_ms * 1e-3) / 1e12,
+                              "roofline": {"bound": "valu", "kernel": "k_full_had<uint16_t>", "achieved": had_exec / (k_had_ms * 1e-3) / 1e12,
                                            "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s",
-                                           "frac": had_ops / (k_had_ms * 1e-3) / (cus * 64 * clk_hz), "kernel_ms": k_had_ms,
+                                           "frac": had_exec / (k_had_ms * 1e-3) / (cus * 64 * clk_hz),
+                                           "algorithmic_achieved": had_ops / (k_had_ms * 1e-3) / 1e12,
+                                           "algorithmic_frac": had_ops / (k_had_ms * 1e-3) / (cus * 64 * clk_hz), "kernel_ms": k_had_ms,
                                            "search_kernel_ms": k_had_tail_ms, "algorithmic_ops_per_launch": had_ops,
-                                           "ops_def": "SA8D evaluation = 7*w*h integer operations; algorithmic = every PU's candidates x its "
-                                                      "own pixels (the kernel prices each 8x8 cell once for the four levels, so frac can exceed 1)"}}
+                                           "executed_ops_per_launch": had_exec,
+                                           "ops_def": "SA8D evaluation = 7*w*h integer operations. frac / achieved: the operations EXECUTED (each 8x8 "
+                                                      "cell of a candidate priced once, 7*64 per cell); algorithmic_*: every PU's candidates x its own "
+                                                      "pixels (the four levels share the cells, so that ratio exceeds 1)"}}
     # the same frame with EVERY partition of the CTUs that is made of 8x8 cells (85 squares + 124 symmetric / asymmetric
     # rectangles per CTU) in one list: one pass over each window prices them all
     parts = [had_jobs]
@@ -553,7 +616,7 @@ def main():
         chk, _ = o.search(seq4[1], [seq4[0]], shape_jobs[ssel], threads=8, bit_depth=10)
         line["sa8d_full_4k10"]["all_shapes"]["parity_sample"] = "%d of %d PUs (every 1201st) equal to the oracle: %s" % (
             len(ssel), len(shape_jobs), bool(np.array_equal(chk, shape_res[ssel])))
-        line["parity_sample_ok"] = ok and bool(np.array_equal(chk, shape_res[ssel]))
+        line["parity_sample_ok"] = ok and ok_pipe and bool(np.array_equal(chk, shape_res[ssel]))
 
     print(json.dumps(line), flush=True)
 

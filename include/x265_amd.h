@@ -109,6 +109,15 @@ int x265amd_plane_create(x265amd_ctx *ctx, int width, int height, int margin_x, 
                          int bytes_per_px, int bit_depth, int *plane_id);
 int x265amd_plane_update_rows(x265amd_ctx *ctx, int plane_id, const void *host_origin, intptr_t host_stride,
                               int y0, int n_rows);
+/* Refill a registered plane (uploaded, created or wrapped) with a new picture of the same geometry,
+ * asynchronously: `host_base` addresses the first byte of a padded plane in page-locked host memory, which
+ * must stay valid until x265amd_sync.  The copy runs on an upload stream of the library: behind every
+ * search queued BEFORE the call (they may still read the old picture), beside everything queued after it
+ * that does not name this plane; a search that names the plane starts behind the copy.  With two sets of
+ * planes an encoder uploads picture k + 1 while picture k is searched - the reference's frame-parallel
+ * hand-over of reconstructed pictures (encoder/frameencoder.cpp:893-918) in picture units.  Pageable
+ * memory works too (the runtime stages it and the call may block). */
+int x265amd_plane_refill_async(x265amd_ctx *ctx, int plane_id, const void *host_base);
 /* geometry a plane was registered with (TComPicYuv::getWidth / getHeight / getLumaMarginX / getStride,
  * Lib/TLibCommon/TComPicYuv.h); any pointer may be NULL */
 int x265amd_plane_geometry(x265amd_ctx *ctx, int plane_id, int *width, int *height, int *margin_x, int *margin_y,
@@ -257,6 +266,14 @@ int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, 
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
 /* wait for the list's last run and copy its results (list length entries) to `out` in host memory */
 int x265amd_joblist_results(x265amd_ctx *ctx, x265amd_joblist *list, x265amd_me_result *out);
+/* queue the copy of the list's results to `out` behind its last run and return at once (page-locked,
+ * device-mapped memory is written by a small kernel on the context's stream; other memory by a DMA copy
+ * on a stream of its own, which only the next run of THIS list waits for).  The caller reads `out` after
+ * x265amd_sync.  `out` should be
+ * page-locked host memory (hipHostMalloc / a pinned tensor); with pageable memory the runtime stages the
+ * copy and the call may block.  This is how a frame's MV field leaves the GPU while the next frame is
+ * searched (the reference hands a PU's result back by return value, encoder/motion.cpp:863-865). */
+int x265amd_joblist_results_async(x265amd_ctx *ctx, x265amd_joblist *list, x265amd_me_result *out);
 /* Reorder the list's launches so that the jobs that took the most block-cost evaluations in its last
  * run start first (results do not depend on the order; a launch ends with its longest searches, and
  * consecutive frames move alike).  Blocks until the last run has finished.  No counterpart in the
@@ -363,6 +380,11 @@ typedef struct x265amd_primitives
  * x265::primitives (common/primitives.cpp:129-139).  bytes_per_px selects the pixel type
  * (1: HIGH_BIT_DEPTH=0, 2: HIGH_BIT_DEPTH=1). */
 int x265amd_setup_primitives(x265amd_primitives *p, int device, int bytes_per_px);
+
+/* Text identifying the build: "x265_amd <hash>", <hash> = SHA-1 (first 12 hex digits) over the library's source
+ * files at build time (x265_amd/build.py), so that a measurement can name the sources of the binary it ran.
+ * The reference's counterpart is x265_version_str (common/version.cpp). */
+const char *x265amd_build_info(void);
 
 /* PartitionFromSizes (common/primitives.cpp:40-54); -1 if not a partition */
 int x265amd_partition_from_sizes(int w, int h);

@@ -55,6 +55,37 @@ def test_4k_three_references_multi_candidate_search(eng, oracle):
         eng.release_plane(i)
 
 
+def test_bench_job_list_sampled_against_the_oracle(eng, oracle):
+    """The exact job list bench.py's headline runs (1080p, exhaustive +-64 SAD search of every square PU 64/32/16/8:
+    42 900 PUs, the bottom CTU row cut at 56 of 64 lines) through a planned list, as the bench does; more than 1000
+    PUs compared with the oracle: a random sample of every level plus every PU of the partial bottom cell row's
+    rightmost and leftmost CTUs (clipped ranges in both directions)."""
+    import bench
+    _, full_jobs = bench.build_job_lists()
+    assert len(full_jobs) == 42900
+    base = synth.base_frame(bench.W, bench.H)
+    ref = synth.pad_plane(base)
+    enc = synth.pad_plane(synth.moved_frame(base, 1))
+    ids = [eng.upload_plane(enc), eng.upload_plane(ref)]
+    jl = eng.make_joblist(full_jobs)
+    got = jl.run(ids[0], [ids[1]])
+    jl.close()
+    rng = np.random.default_rng(2025)
+    pick = []
+    for size, count in ((64, 10), (32, 40), (16, 250), (8, 700)):
+        idx = np.nonzero(full_jobs["w"] == size)[0]
+        pick.append(rng.choice(idx, count, replace=False))
+    bottom = np.nonzero((full_jobs["pu_y"] >= 1024) & ((full_jobs["pu_x"] < 64) | (full_jobs["pu_x"] >= bench.W - 64)))[0]
+    assert len(bottom) > 80
+    sel = np.unique(np.concatenate(pick + [bottom]))
+    assert len(sel) >= 1000
+    exp, _ = oracle.search(enc, [ref], np.ascontiguousarray(full_jobs[sel]), threads=8)
+    bad = np.nonzero(got[sel] != exp)[0]
+    assert bad.size == 0, (len(bad), full_jobs[sel][bad[:3]], got[sel][bad[:3]], exp[bad[:3]])
+    for i in ids:
+        eng.release_plane(i)
+
+
 # the PU shapes of one 64x64 CTU: 2Nx2N, 2NxN, Nx2N at depths 0-3, AMP at depths 0-2, 8x4 / 4x8 at depth 3
 HEVC_PU_SHAPES = [(64, 64), (64, 32), (32, 64), (64, 16), (64, 48), (16, 64), (48, 64),
                   (32, 32), (32, 16), (16, 32), (32, 8), (32, 24), (8, 32), (24, 32),
@@ -161,3 +192,36 @@ def test_4k_lookahead_batch_through_plane_ring(oracle):
         jls[k].close()
     eng.close()
     dist.destroy_process_group()
+
+
+def test_planes_refilled_and_fields_fetched_asynchronously(eng, oracle):
+    """Pipelined frames: two sets of planes refilled from page-locked host memory beside the searches
+    (x265amd_plane_refill_async) and every frame's field fetched behind its search into page-locked memory
+    (x265amd_joblist_results_async), the host waiting once at the end - every frame's field must be the oracle's for
+    THAT frame's pictures (a refill that started too early or a search that did not wait for one would mix frames)."""
+    import torch
+    W, H, NF = 416, 240, 6
+    fr = synth.make_sequence(W, H, NF + 1, seed=41)
+    pins = [torch.from_numpy(f).pin_memory() for f in fr]
+    jobs = np.concatenate([J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=1, merange=24, qp=30),
+                           J.frame_jobs(W, H, sizes=(16, 8), method=J.HEX, subme=5, merange=32, qp=30)])
+    sets = [{"enc": eng.upload_plane(fr[1]), "ref": eng.upload_plane(fr[0])}, {"enc": eng.create_plane(W, H), "ref": eng.create_plane(W, H)}]
+    jls = [eng.make_joblist(jobs) for _ in range(NF)]
+    outs = [torch.zeros(len(jobs) * 8, dtype=torch.uint8).pin_memory() for _ in range(NF)]
+    for k in range(NF):                     # frame k: picture k + 1 against picture k; nothing in this loop waits
+        if k + 1 < NF:
+            nxt = sets[(k + 1) & 1]
+            eng.refill_plane_async(nxt["enc"], pins[k + 2].data_ptr())
+            eng.refill_plane_async(nxt["ref"], pins[k + 1].data_ptr())
+        st = sets[k & 1]
+        jls[k].run(st["enc"], [st["ref"]], fetch=False)
+        jls[k].results_async(outs[k].data_ptr())
+    eng.sync()
+    for k in range(NF):
+        exp, _ = oracle.search(fr[k + 1], [fr[k]], jobs, threads=8)
+        got = outs[k].numpy().view(J.RESULT_DTYPE)
+        assert np.array_equal(got, exp), (k, np.nonzero(got != exp)[0][:5])
+        jls[k].close()
+    for st in sets:
+        eng.release_plane(st["enc"])
+        eng.release_plane(st["ref"])

@@ -12,6 +12,10 @@ if "hex_search" in d:
     print("dia: %.4g evals/s  ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"]))
     p = d["pcie_inclusive"]
     print("pcie-inclusive ms/frame: full %.4f  hex %.4f" % (p["full_search"]["ms_per_frame"], p["hex_search"]["ms_per_frame"]))
+    if "pipelined" in p:
+        q = p["pipelined"]
+        print("  pipelined: full %.4f (%.3f x resident, field equal %s)  hex %.4f" % (q["full_search"]["ms_per_frame"], q["vs_resident"],
+              q["full_search"]["field_equals_resident_run"], q["hex_search"]["ms_per_frame"]))
 if "sa8d_full_4k10" in d:
     s = d["sa8d_full_4k10"]
     print("sa8d 4K 10-bit: %.4g evals/s  ms/frame %.3f  k_full_had %.3f ms  tail %.3f ms" %

@@ -102,6 +102,10 @@ def load_library() -> C.CDLL:
     L.x265amd_joblist_results_device.argtypes = [vp]
     L.x265amd_joblist_results_device.restype = vp
     L.x265amd_joblist_results.argtypes = [vp, vp, vp]
+    L.x265amd_joblist_results_async.argtypes = [vp, vp, vp]
+    L.x265amd_plane_refill_async.argtypes = [vp, C.c_int, vp]
+    L.x265amd_build_info.argtypes = []
+    L.x265amd_build_info.restype = C.c_char_p
     L.x265amd_joblist_destroy.argtypes = [vp, vp]
     L.x265amd_joblist_rebalance.argtypes = [vp, vp]
     L.x265amd_eval_count.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
@@ -223,6 +227,10 @@ class Engine:
         """copy rows [y0, y0 + n_rows) of an UNPADDED picture array into the plane and extend their borders"""
         assert picture.flags["C_CONTIGUOUS"]
         self._chk(self.lib.x265amd_plane_update_rows(self.h, pid, picture.ctypes.data, picture.shape[1], y0, n_rows))
+
+    def refill_plane_async(self, pid: int, host_ptr: int):
+        """queue the upload of a whole padded plane (page-locked host memory at `host_ptr`) into plane `pid`; no wait"""
+        self._chk(self.lib.x265amd_plane_refill_async(self.h, pid, host_ptr))
 
     def release_plane(self, pid: int):
         self._chk(self.lib.x265amd_plane_release(self.h, pid))
@@ -377,6 +385,10 @@ class JobList:
         self.eng._chk(self.eng.lib.x265amd_joblist_results(self.eng.h, self.h, out.ctypes.data))
         return out
 
+    def results_async(self, out_ptr: int):
+        """queue the copy of the last run's results to page-locked host memory at `out_ptr` (n * 8 bytes); no wait"""
+        self.eng._chk(self.eng.lib.x265amd_joblist_results_async(self.eng.h, self.h, out_ptr))
+
     def rebalance(self):
         """start the jobs that were longest in the last run first in the following runs"""
         self.eng._chk(self.eng.lib.x265amd_joblist_rebalance(self.eng.h, self.h))
@@ -389,6 +401,11 @@ class JobList:
         if self.h and self.eng.h:
             self.eng.lib.x265amd_joblist_destroy(self.eng.h, self.h)
         self.h = None
+
+
+def build_info() -> str:
+    """x265amd_build_info: names the sources the loaded library was built from"""
+    return load_library().x265amd_build_info().decode()
 
 
 def setup_primitives(device: int = 0, bytes_per_px: int = 1) -> Primitives:

@@ -17,6 +17,16 @@ MAIN_ONLY_H = [os.path.join(HERE, "csrc", f) for f in ("me_full.h", "me_hier.h",
 DEPS = [SRC, PART, PUBLIC_H] + PART_H + MAIN_ONLY_H
 
 
+def source_hash() -> str:
+    """SHA-1 (12 hex digits) over the library's sources, in a fixed order: what x265amd_build_info() reports"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(d for d in DEPS if os.path.exists(d)):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
@@ -46,7 +56,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # of flags rebuilds everything)
     stamp = os.path.join(objdir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
-    jobs = [([hipcc, *flags, "-c", "-o", os.path.join(objdir, "main.o"), SRC], [SRC, PUBLIC_H] + PART_H + MAIN_ONLY_H)]
+    # (the source hash goes into the main unit only, which is rebuilt whenever any source changes anyway)
+    jobs = [([hipcc, *flags, '-DXA_SRC_HASH="%s"' % source_hash(), "-c", "-o", os.path.join(objdir, "main.o"), SRC], [SRC, PUBLIC_H] + PART_H + MAIN_ONLY_H)]
     for k in range(1, N_PARTS + 1):
         jobs.append(([hipcc, *flags, "-DXA_PART=%d" % k, "-c", "-o", os.path.join(objdir, "part%d.o" % k), PART], [PART, PUBLIC_H] + PART_H))
     objs = [c[c.index("-o") + 1] for c, _ in jobs]

@@ -53,6 +53,36 @@ struct DevBuf
 
 constexpr int EVAL_WORDS = (EVAL_SLOTS + 2) * 16;   // device words behind d_evals
 
+// results to device-mapped host memory, one 64-bit word per thread
+__global__ void __launch_bounds__(256) k_copy_words(const unsigned long long *src, unsigned long long *dst, int n)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n)
+        dst[i] = src[i];
+}
+
+// A padded plane from device-mapped host memory.  Few workgroups on purpose: the reads cross the bus with microseconds
+// of latency, and a launch that floods the memory pipeline with them holds up the search kernels' own reads (a
+// bus-wide launch stretched a concurrent k_pack_fenc from 6 to 60 us and a pipelined 1080p frame from 0.52 to 0.65 ms; with
+// 4 workgroups it is 0.55 ms, with 24: 0.58); each thread keeps four 16-byte reads in flight, which is enough for the
+// copy to finish well inside the search of the picture before.
+constexpr int COPY_WGS = 4;
+__global__ void __launch_bounds__(256) k_copy_bytes(const unsigned char *src, unsigned char *dst, size_t bytes)
+{
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride)
+    {
+        const uint4 a = ((const uint4*)src)[i], b = ((const uint4*)src)[i + stride], c = ((const uint4*)src)[i + 2 * stride],
+                    d = ((const uint4*)src)[i + 3 * stride];
+        ((uint4*)dst)[i] = a; ((uint4*)dst)[i + stride] = b; ((uint4*)dst)[i + 2 * stride] = c; ((uint4*)dst)[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride)
+        ((uint4*)dst)[i] = ((const uint4*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < bytes - 16 * n16)
+        dst[16 * n16 + threadIdx.x] = src[16 * n16 + threadIdx.x];
+}
+
 struct x265amd_ctx
 {
     int          device = 0;
@@ -90,6 +120,16 @@ struct x265amd_ctx
     int n_lanes = 2;                       // streams in use: 1 .. N_AUX + 1 (X265AMD_LANES); two give the overlap, more only cost hardware queues
     hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
+    // planes refilled asynchronously (x265amd_plane_refill_async): the upload stream, a marker event of the main stream,
+    // and per plane the event behind its last refill (a search that names the plane waits for it)
+    hipStream_t up_stream = nullptr;
+    bool        up_stream_owned = false;
+    hipEvent_t  ev_mark = nullptr;
+    hipEvent_t  plane_filled[MAX_PLANES] = {};
+    bool        fill_pending[MAX_PLANES] = {};
+    // results leave on a stream of their own (x265amd_joblist_results_async), so that a download does not hold up the
+    // next batch on the main stream; created on first use
+    hipStream_t out_stream = nullptr;
     x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
     hipStream_t lane(int k) const { return (k % n_lanes) == 0 ? stream : aux[(k % n_lanes) - 1]; }
 };
@@ -113,6 +153,8 @@ struct x265amd_joblist
     bool    has_fb = false;               // some job's integer stage runs in an exhaustive kernel
     std::vector<int> order;               // host copy of idx
     bool    ran = false;
+    hipEvent_t ev_ran = nullptr, ev_out = nullptr;   // behind the last run / behind the last asynchronous download of the results
+    bool    out_pending = false;          // a download may still read `results`: the next run waits for ev_out
     bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
     int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., lane-per-job class ...]
     struct Launch { int first, count, lds_bytes, w4; };
@@ -268,6 +310,21 @@ int check_batch_planes(x265amd_ctx *c, int enc_plane, const int *ref_planes, int
             return fail(c, X265AMD_ERR_INVALID, "ref plane is not a registered plane");
         if (c->h_planes[r].bpp != c->h_planes[enc_plane].bpp)
             return fail(c, X265AMD_ERR_INVALID, "enc and ref planes differ in pixel size");
+    }
+    return 0;
+}
+
+// searches that name a plane with a refill in flight start behind it
+int wait_plane_fills(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs)
+{
+    for (int k = -1; k < n_refs; k++)
+    {
+        const int id = k < 0 ? enc_plane : ref_planes[k];
+        if (c->fill_pending[id])
+        {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->plane_filled[id], 0));
+            c->fill_pending[id] = false;
+        }
     }
     return 0;
 }
@@ -1027,6 +1084,10 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
+    if (c->out_stream)
+        hipStreamSynchronize(c->out_stream);
+    if (L->ev_ran) hipEventDestroy(L->ev_ran);
+    if (L->ev_out) hipEventDestroy(L->ev_out);
     DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
                        &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->had_quads,
                        &L->fb_jobs };
@@ -1134,6 +1195,11 @@ int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams 
 
 int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
+    if (L->out_pending)
+    {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L->ev_out, 0));      // the last download has read the result buffer
+        L->out_pending = false;
+    }
     if (int rc = record_start(c)) return rc;
     if (int rc = joblist_launch_full(c, L, P)) return rc;
     c->timed_full = L->has_fb;
@@ -1295,6 +1361,13 @@ void x265amd_destroy(x265amd_ctx *c)
         return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->up_stream)
+    {
+        hipStreamSynchronize(c->up_stream);
+        if (c->up_stream_owned)
+            hipStreamDestroy(c->up_stream);
+        hipEventDestroy(c->ev_mark);
+    }
     for (int i = 0; i < MAX_PLANES; i++)
         if (c->used[i] && c->owned[i])
             hipFree(c->owned[i]);
@@ -1324,6 +1397,10 @@ void x265amd_destroy(x265amd_ctx *c)
         if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->out_stream) hipStreamDestroy(c->out_stream);
+    for (int i = 0; i < MAX_PLANES; i++)
+        if (c->plane_filled[i])
+            hipEventDestroy(c->plane_filled[i]);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1335,6 +1412,10 @@ int x265amd_sync(x265amd_ctx *c)
     if (!c)
         return X265AMD_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->out_stream)
+        HIPCHK(c, hipStreamSynchronize(c->out_stream));       // asynchronous result downloads
+    if (c->up_stream)
+        HIPCHK(c, hipStreamSynchronize(c->up_stream));        // asynchronous plane refills
     return 0;
 }
 
@@ -1480,6 +1561,53 @@ int x265amd_plane_update_rows(x265amd_ctx *c, int id, const void *host_origin, i
     return 0;
 }
 
+int x265amd_plane_refill_async(x265amd_ctx *c, int id, const void *host_base)
+{
+    if (!c || !host_base || id < 0 || id >= MAX_PLANES || !c->used[id])
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const PlaneDesc &d = c->h_planes[id];
+    if (d.lr_step)
+        return fail(c, X265AMD_ERR_INVALID, "a half-resolution set is refilled with x265amd_lowres_update");
+    if (!c->up_stream)
+    {
+        // (a process has few hardware queues, and streams beyond them share one - in packet order, which would put the
+        // searches behind the uploads: take the context's last auxiliary stream when the launches do not use it)
+        if (c->n_lanes <= x265amd_ctx::N_AUX)
+            c->up_stream = c->aux[x265amd_ctx::N_AUX - 1];
+        else
+        {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+            c->up_stream_owned = true;
+        }
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+    }
+    if (!c->plane_filled[id])
+        HIPCHK(c, hipEventCreateWithFlags(&c->plane_filled[id], hipEventDisableTiming));
+    // behind everything queued so far (the searches that read the plane's old content), beside everything queued later
+    // that does not name this plane
+    HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->ev_mark, 0));
+    const size_t bytes = (size_t)(d.hi - d.lo) * d.bpp;
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, const_cast<void*>(host_base), 0) == hipSuccess && mapped)
+    {
+        // page-locked, device-mapped memory: read over the bus by a copy kernel (no DMA submission on the host's path)
+        hipLaunchKernelGGL(k_copy_bytes, dim3(COPY_WGS), dim3(256), 0, c->up_stream,
+                           (const unsigned char*)mapped, (unsigned char*)c->base[id], bytes);
+        HIPCHK(c, hipGetLastError());
+    }
+    else
+    {
+        (void)hipGetLastError();
+        HIPCHK(c, hipMemcpyAsync(c->base[id], host_base, bytes, hipMemcpyHostToDevice, c->up_stream));
+    }
+    HIPCHK(c, hipEventRecord(c->plane_filled[id], c->up_stream));
+    c->fill_pending[id] = true;
+    return 0;
+}
+
 void *x265amd_plane_device_ptr(x265amd_ctx *c, int id)
 {
     if (!c || id < 0 || id >= MAX_PLANES || !c->used[id])
@@ -1494,6 +1622,9 @@ int x265amd_plane_release(x265amd_ctx *c, int id)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->up_stream)
+        HIPCHK(c, hipStreamSynchronize(c->up_stream));
+    c->fill_pending[id] = false;
     if (c->owned[id])
         hipFree(c->owned[id]);
     c->used[id] = false;
@@ -2030,6 +2161,7 @@ int x265amd_me_search_batch(x265amd_ctx *c, int enc_plane, const int *ref_planes
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = wait_plane_fills(c, enc_plane, ref_planes, n_refs)) return rc;
     bool any_full = false;
     if (int rc = validate_jobs(c, jobs, n, n_refs, &any_full)) return rc;
     if (int rc = check_job_ranges(c, enc_plane, ref_planes, jobs, n)) return rc;
@@ -2067,6 +2199,7 @@ int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = wait_plane_fills(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = sync_planes(c)) return rc;
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
     if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
@@ -2092,6 +2225,7 @@ int x265amd_me_search_batch_device_noalloc(x265amd_ctx *c, int enc_plane, const 
         return fail(c, X265AMD_ERR_INVALID, msg);
     }
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = wait_plane_fills(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = sync_planes(c)) return rc;          // (a copy from pinned memory; nothing is allocated)
     // every context on this GPU shares the array: order this call behind the last one that used it
     std::lock_guard<std::mutex> gs(g_scratch_mu);
@@ -2138,6 +2272,7 @@ int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
+    if (int rc = wait_plane_fills(c, enc_plane, ref_planes, n_refs)) return rc;
     if (c->h_planes[enc_plane].bpp != L->bpp)
         return fail(c, X265AMD_ERR_INVALID, "job list was planned for a different pixel size");
     if (n_refs < L->n_refs)
@@ -2186,6 +2321,48 @@ int x265amd_joblist_results(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_resul
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+
+int x265amd_joblist_results_async(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_result *out)
+{
+    if (!c || !L || !out)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!L->ran)
+        return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    // Page-locked, device-mapped host memory is written by a small kernel behind the run on the main stream (a few
+    // microseconds; queueing a DMA copy costs the host about 0.1 ms per call on this platform, and one more stream
+    // would share a hardware queue with the caller's upload stream).  Anything else: hipMemcpyAsync on a stream of
+    // its own, so that the batches queued next do not wait for it.
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, out, 0) == hipSuccess && mapped)
+    {
+        static_assert(sizeof(x265amd_me_result) == 8, "one result = one 64-bit word");
+        hipLaunchKernelGGL(k_copy_words, dim3((L->n + 255) / 256), dim3(256), 0, c->stream,
+                           (const unsigned long long*)L->results.p, (unsigned long long*)mapped, L->n);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    (void)hipGetLastError();
+    if (!c->out_stream)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+    if (!L->ev_ran)
+    {
+        HIPCHK(c, hipEventCreateWithFlags(&L->ev_ran, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&L->ev_out, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(L->ev_ran, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->out_stream, L->ev_ran, 0));
+    HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipEventRecord(L->ev_out, c->out_stream));
+    L->out_pending = true;
+    return 0;
+}
+
+#ifndef XA_SRC_HASH
+#define XA_SRC_HASH "unknown"
+#endif
+const char *x265amd_build_info(void) { return "x265_amd " XA_SRC_HASH; }
 
 // Launch order by job length.  A pattern search's length is data dependent (a far-moving block takes
 // three times the evaluations of a still one) and the general kernel's launch ends with its longest
