@@ -97,6 +97,140 @@ def cpu_baseline(budget_s=6.0):
     return out
 
 
+def sharded_legs(eng, dev, rank, world, args, barrier, dist):
+    """BASELINE configs[3] and configs[4] as they shard over N ranks (run at every N, N = 1 included):
+      lookahead_batch_4k  8 current 4K frames against the same two references: frame i -> rank i mod N; the references are
+                          uploaded on rank 0 and broadcast ONCE per batch (RCCL); every rank searches its frames (HEX +
+                          subme 5, 16x16 and 64x64 PUs, both references) - fixed total work, "strong" over the batch;
+      sa8d_all_shapes_4k10  4K 10-bit, all 593 PUs of every CTU, exhaustive +-16 SA8D search: one frame per rank against a
+                          broadcast reference (18.6 MB) - "weak" like the headline.
+    Every rank compares a sample of its own results with the oracle; the line carries the AND over the ranks."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as F
+    from x265_amd import dist as xd
+    W4, H4, NF = 3840, 2160, 8
+    out = {}
+    grouped = dist is not None and dist.is_initialized()
+    red_dev = dev if (grouped and dist.get_backend() == "nccl") else "cpu"
+
+    def reduce(v, op):
+        if not grouped:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def bcast(t):
+        # one collective per reference plane, ordered against the engine's stream on the GPU (no host wait)
+        t0 = time.perf_counter()
+        xd.broadcast_plane(t, 0, engine=eng)
+        eng.sync()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e6
+
+    oracle = F.Oracle()
+    # ---- configs[3]: the 8-frame batch
+    seq = synth.make_sequence(W4, H4, NF + 2, seed=99)            # frames 0, 1: the references; 2 .. 9: the batch
+    stride = seq[0].shape[1]
+    refs = [torch.from_numpy(seq[i]).to(dev) if rank == 0 else torch.zeros(seq[i].shape, dtype=torch.uint8, device=dev) for i in range(2)]
+    ref_ids = [eng.wrap_device_plane(t.data_ptr(), W4, H4, stride, 1, 8) for t in refs]
+    mine = xd.shard_frames(NF, rank, world)
+    encs = {f: torch.from_numpy(seq[2 + f]).to(dev) for f in mine}
+    enc_ids = {f: eng.wrap_device_plane(encs[f].data_ptr(), W4, H4, stride, 1, 8) for f in mine}
+    jobs = np.concatenate([J.frame_jobs(W4, H4, sizes=(64, 16), method=J.HEX, subme=5, merange=64, qp=32, ref_idx=r) for r in range(2)])
+    jls = {f: eng.make_joblist(jobs, n_refs=2) for f in mine}
+    times, bus = [], []
+    for rep in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        b_us = sum(bcast(t) for t in refs) if grouped else 0.0     # once per batch
+        for f in mine:
+            jls[f].run(enc_ids[f], ref_ids, fetch=False)
+        eng.sync()
+        barrier()
+        times.append(time.perf_counter() - t0)
+        bus.append(b_us)
+    dt = reduce(min(times), dist.ReduceOp.MAX if grouped else None)
+    eng.eval_count(reset=True)
+    for f in mine:
+        jls[f].run(enc_ids[f], ref_ids, fetch=False)
+    evals = reduce(eng.eval_count(), dist.ReduceOp.SUM if grouped else None)
+    ok = 1.0
+    if mine:
+        f = mine[0]
+        sel = np.arange(rank, len(jobs), 211)
+        exp, _ = oracle.search(seq[2 + f], [seq[0], seq[1]], np.ascontiguousarray(jobs[sel]), threads=8)
+        ok = float(np.array_equal(jls[f].results()[sel], exp))
+    ok = reduce(ok, dist.ReduceOp.MIN if grouped else None)
+    out["lookahead_batch_4k"] = {"workload": "BASELINE configs[3]: 8 current 4K 8-bit frames against the same 2 references, frame i -> rank i mod N, "
+                                             "references broadcast from rank 0 once per batch; HEX + subme 5, 16x16 + 64x64 PUs, both references "
+                                             "(%d jobs per frame)" % len(jobs),
+                                 "scaling": "strong (the batch is fixed)", "frames": NF, "batch_ms": dt * 1e3, "frames_per_s": NF / dt,
+                                 "value": evals / dt, "unit": "evals/s", "reference_broadcast_us": reduce(min(bus), dist.ReduceOp.MAX if grouped else None),
+                                 "reference_bytes": int(2 * seq[0].nbytes), "parity_sample_ok_all_ranks": bool(ok)}
+    for f in mine:
+        jls[f].close()
+        eng.release_plane(enc_ids[f])
+    for i in ref_ids:
+        eng.release_plane(i)
+    del refs, encs
+    # ---- configs[4]: 4K 10-bit, every PU shape, SA8D, one frame per rank
+    seq4 = synth.make_sequence(W4, H4, world + 1, seed=5, bit_depth=10)
+    # (16-bit planes travel as bytes: the collective library has no 16-bit integer type)
+    ref4 = torch.from_numpy(seq4[0].view(np.uint8)).to(dev) if rank == 0 else torch.zeros(seq4[0].view(np.uint8).shape, dtype=torch.uint8, device=dev)
+    enc4 = torch.from_numpy(seq4[rank + 1].view(np.uint8)).to(dev)
+    rid = eng.wrap_device_plane(ref4.data_ptr(), W4, H4, seq4[0].shape[1], 2, 10)
+    eid = eng.wrap_device_plane(enc4.data_ptr(), W4, H4, seq4[0].shape[1], 2, 10)
+    shape_jobs = J.all_partition_jobs(W4, H4, method=J.FULL, subme=0, merange=16, qp=27, icost=J.SA8D)
+    jl = eng.make_joblist(shape_jobs, bytes_per_px=2)
+    b_us = bcast(ref4) if grouped else 0.0
+    for _ in range(2):
+        jl.run(eid, [rid], fetch=False)
+    eng.sync()
+    eng.eval_count(reset=True)
+    steps = 5
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if grouped:
+            xd.broadcast_plane(ref4, 0, engine=eng)               # a new reference every frame: the exchange step inside the timed region
+        jl.run(eid, [rid], fetch=False)
+    eng.sync()
+    barrier()
+    dt = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX if grouped else None)
+    evals = reduce(eng.eval_count(), dist.ReduceOp.SUM if grouped else None)
+    sel = np.arange(rank, len(shape_jobs), 4801)
+    exp, _ = oracle.search(seq4[rank + 1], [seq4[0]], np.ascontiguousarray(shape_jobs[sel]), threads=8, bit_depth=10)
+    ok = reduce(float(np.array_equal(jl.results()[sel], exp)), dist.ReduceOp.MIN if grouped else None)
+    out["sa8d_all_shapes_4k10"] = {"workload": "BASELINE configs[4]: 4K 10-bit, all 593 PUs of every CTU (24 shapes), exhaustive +-16 SA8D search; one frame "
+                                               "per rank per step against a reference broadcast from rank 0 every step (%d jobs per frame)" % len(shape_jobs),
+                                   "scaling": "weak", "ms_per_step": dt / steps * 1e3, "frames_per_s": world * steps / dt, "value": evals / dt,
+                                   "unit": "evals/s", "reference_broadcast_us": reduce(b_us, dist.ReduceOp.MAX if grouped else None),
+                                   "reference_bytes": int(seq4[0].nbytes), "parity_sample_ok_all_ranks": bool(ok)}
+    jl.close()
+    eng.release_plane(rid)
+    eng.release_plane(eid)
+    return out
+
+
+class stdout_to_stderr:
+    """The collective library prints a version banner on the process's stdout when it initialises; this script's stdout is ONE
+    JSON line, so file descriptor 1 points at stderr while a process group comes up and runs its first collective."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def trace(msg):
     if os.environ.get("X265AMD_BENCH_TRACE"):
         print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
@@ -140,10 +274,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(warm)                   # the communicator comes up here
+            torch.cuda.synchronize()
+    group_backend = backend if world > 1 else None
 
     if os.environ.get("X265AMD_BENCH_TRACE"):       # a stuck rank shows where it is
         import faulthandler
@@ -194,6 +333,7 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
 
     step_no = [0]
+    host_queue = [0.0]
 
     def step(jl):
         # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame; no host waits
@@ -228,6 +368,7 @@ def main():
             if k == steps - 1:
                 eng.set_timing(True)
             step(jl)
+        host_queue[0] = (time.perf_counter() - t0) / steps * 1e6      # the host's time to queue a step (no GPU wait in it)
         eng.sync()
         barrier()
         dt = time.perf_counter() - t0
@@ -265,6 +406,7 @@ def main():
     full = hexr = None
     if run_full:
         fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, args.warmup, args.steps)
+        full_host_queue_us = host_queue[0]
         full_res = jl_full.run(enc_id, [ref_id], fetch=True)
         px_alg = pixel_sads(full_jobs)                    # 1 evaluation of a w x h block = w*h pixel-SADs, no credit for reuse
         px_exec = float(J.full_search_evals(full_jobs[full_jobs["w"] == 8]) * 64)      # measured: the 8x8 cells only
@@ -330,14 +472,14 @@ def main():
 
     # ---- the exchange step alone (N > 1): reference plane from rank 0 to every rank ----------------
     bcast_us = None
-    if world > 1:
+    if world > 1 or (group_backend and not str(group_backend).startswith("none")):
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             xd.broadcast_plane(ref_bufs[0], 0, engine=eng)
         eng.sync()
         barrier()
-        t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e6], dtype=torch.float64, device=dev)
+        t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e6], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         bcast_us = float(t.item())
 
@@ -366,15 +508,46 @@ def main():
                    "jobs_per_frame": int(len(full_jobs)), "evals_per_frame": full["evals_per_frame"],
                    "qp": QP, "merange": MERANGE, "parallelism": "frames sharded over %d GPU(s)" % world,
                    # the collective alone, host-bracketed (it is also inside every timed step, beside the searches)
-                   "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes)},
+                   "reference_broadcast_us": bcast_us, "reference_plane_bytes": int(ref_np.nbytes),
+                   "process_group": group_backend,
+                   # the host's share of a step: ring acquire / prefetch / release (collective + events) and the list's launches
+                   "host_queue_us_per_step": full_host_queue_us,
+                   "host_queue_frac_of_step": full_host_queue_us / (full["ms_per_step"] * 1e3)},
         "roofline": full["roofline"],
         "roofline_hbm": full["roofline_hbm"],
         "cpu_baseline": None,
         "library": library_id,
     }
 
-    # With N > 1 only the leg `value` is quoted on runs (plus the broadcast alone): the secondary legs are
-    # single-GPU figures, and every extra step on N ranks is one more collective per rank for nothing.
+    if world == 1 and not args.only_primary and not os.environ.get("X265AMD_NO_GROUP"):
+        # A group of ONE rank, so that the collectives of the N > 1 path run at N = 1 too: the headline step again with the
+        # reference broadcast in every step (what the host pays to queue a step with the collective on), then the sharded legs.
+        try:
+            with stdout_to_stderr():
+                group_backend = xd.single_rank_group(dev)
+                warm = torch.zeros(1, device=dev if group_backend == "nccl" else "cpu")
+                dist.all_reduce(warm)               # the communicator comes up here
+                torch.cuda.synchronize()
+        except Exception as e:      # the legs below then run without collectives and say so
+            group_backend = "none (%s)" % type(e).__name__
+        if dist.is_initialized():
+            ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=bool(os.environ.get("X265AMD_OVERLAP")))
+            step_no[0] = 0
+            cdt, _, _, _ = timed(jl_full, 3, 20)
+            line["config"]["with_one_rank_group"] = {"process_group": group_backend, "ms_per_step": cdt / 20 * 1e3,
+                                                     "host_queue_us_per_step": host_queue[0],
+                                                     "host_queue_frac_of_step": host_queue[0] / (cdt / 20 * 1e6),
+                                                     "note": "the headline step with a reference broadcast in it (one-rank RCCL group): ring acquire / "
+                                                             "release, the collective, the list's launches; host_queue = the host's time to queue a step"}
+    if not args.only_primary:
+        try:
+            line["sharded"] = sharded_legs(eng, dev, rank, world, args, barrier, dist if (world > 1 or dist.is_initialized()) else None)
+        except Exception as e:      # (the headline above stands on its own; a failure here is reported, not hidden)
+            import traceback
+            line["sharded"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback": traceback.format_exc()[-1500:]}
+
+    # With N > 1 the legs above run (the one `value` is quoted on, the broadcast alone, the two sharded 4K legs): the
+    # other secondary legs are single-GPU figures.
     if args.only_primary or world > 1:
         if rank == 0:
             line["note"] = "primary leg only (--only-primary, or N > 1: cpu_baseline and the secondary legs are reported at N = 1)"

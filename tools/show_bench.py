@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print the headline numbers of a bench.py JSON line."""
 import json, sys
-d = json.load(open(sys.argv[1]))
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
 r = d["roofline"]
 print("value %.4g %s  ms_per_step %.4f  exhaustive kernels %.4f ms (frac %.3f, executed %.3f)  tail %.4f ms  parity %s" %
       (d["value"], d["unit"], d["ms_per_step"], r["kernel_ms"], r["frac"], r.get("executed_frac", 0), r.get("search_kernel_ms", 0),

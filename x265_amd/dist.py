@@ -26,6 +26,25 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def single_rank_group(device=None) -> str:
+    """A process group of ONE rank (RCCL on `device` when it initialises, else gloo), so that the collectives of the
+    multi-GPU path really run on a single GPU; returns the backend name.  Does nothing if a group exists."""
+    if dist.is_initialized():
+        return dist.get_backend()
+    import os
+    port = 29700 + (os.getpid() % 200)
+    last = None
+    for backend in (("nccl", "gloo") if device is not None else ("gloo",)):
+        try:
+            kw = {"device_id": device} if backend == "nccl" else {}
+            dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+            return backend
+        except Exception as e:      # pragma: no cover - depends on the box
+            last = e
+            port += 1
+    raise last
+
+
 def shard_frames(n_frames: int, rank_: int, world_: int) -> List[int]:
     """Frames of a batch owned by `rank_`: frame i -> rank i % world (frame i of an 8-frame
     lookahead batch runs on GPU i when world == 8)."""
