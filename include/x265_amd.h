@@ -193,6 +193,18 @@ typedef struct x265amd_mc_pair
 int x265amd_mc_cost_batch(x265amd_ctx *ctx, int kind, int w, int h, int n,
                           const x265amd_mc_pair *pairs, int32_t *out);
 
+/* The source blocks of bidirectional-refinement searches, made on the device: for each of the n w x h PUs,
+ *   dst_plane[PU] = ClipY(2 * enc_plane[PU] - pred),  pred = the motion-compensated prediction of the PU from
+ * ref_plane at the q-pel MV (the OTHER list's best uni-directional MV),
+ * which is what TEncSearch::xMotionEstimation prepares on the host before a bi-predictive search
+ * (fencYuv->copyPartToPartYuv + TComYuv::removeHighFreq against m_predYuv[1 - list],
+ * Lib/TLibEncoder/TEncSearch.cpp:2970-2980, Lib/TLibCommon/TComYuv.cpp:673-702; the prediction as
+ * TComPrediction::xPredInterLumaBlk makes it, Lib/TLibCommon/TComPrediction.cpp:464-496).  dst_plane is a
+ * registered full-resolution plane of the pictures' geometry (e.g. from x265amd_plane_create); X265AMD_BIPRED
+ * jobs queued afterwards with it as their encoder plane search the blocks without a host round trip.
+ * Asynchronous on the context's stream; `pairs` is borrowed only during the call. */
+int x265amd_bipred_source_batch(x265amd_ctx *ctx, int dst_plane, int w, int h, int n, const x265amd_mc_pair *pairs);
+
 /* ---- batched motion search ------------------------------------------------------------
  * One job == one MotionEstimate::motionEstimate call (encoder/motion.h:95,
  * encoder/motion.cpp:277-866) preceded by setQP / setSearchMethod / setSubpelRefine /

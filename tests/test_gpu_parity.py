@@ -576,6 +576,69 @@ def test_bidirectional_refinement_matches_reference_vectors(eng, oracle, bits):
 
 
 @pytest.mark.parametrize("bits", [8, 16])
+def test_bipred_source_blocks_made_on_the_device(eng, oracle, bits):
+    """The block a bidirectional search runs on, ClipY(2 * org - otherPred) (TComYuv::removeHighFreq), made on the device from
+    the original picture and the other list's reference at a q-pel MV (all four interpolation cases, MVs that reach into
+    the margins), compared pixel for pixel with the same block built from the oracle's filter primitives; then
+    X265AMD_BIPRED jobs on the device-made plane against the oracle searching the host-made plane."""
+    depth = 8 if bits == 8 else 10
+    dt = np.uint8 if bits == 8 else np.uint16
+    W, H, M = 256, 160, synth.MARGIN
+    fr = synth.make_sequence(W, H, 3, seed=91, bit_depth=depth)         # 0: original, 1: this list's reference, 2: the other list's
+    rng = np.random.default_rng(4)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    dst = eng.create_plane(W, H, bytes_per_px=bits // 8, bit_depth=depth)
+    host_dst = np.zeros_like(fr[0])
+    all_jobs = []
+    for (w, h) in ((64, 64), (32, 16), (16, 16), (8, 8), (8, 4), (4, 16)):
+        xs = np.arange(0, W - w + 1, w)[:4]
+        ys = np.arange(0, H - h + 1, h)[:2]
+        gx, gy = (a.ravel() for a in np.meshgrid(xs, ys))
+        pairs = np.zeros(len(gx), dtype=api_mc_dtype())
+        pairs["enc_plane"], pairs["ref_plane"] = ids[0], ids[2]
+        pairs["pu_x"], pairs["pu_y"] = gx, gy
+        pairs["qmv_x"] = rng.integers(-40, 40, len(gx))
+        pairs["qmv_y"] = rng.integers(-40, 40, len(gx))
+        pairs["qmv_x"][0], pairs["qmv_y"][0] = -(gx[0] + 60) * 4 - 2, 8          # far into the left margin
+        pairs["qmv_x"][1:5] = (4, 6, 8, 5)
+        pairs["qmv_y"][1:5] = (8, 4, 7, 4)                                       # integer, H, V and HV phases for sure
+        eng.bipred_source_batch(dst, w, h, pairs)
+        for p in pairs:
+            qx, qy, px, py = int(p["qmv_x"]), int(p["qmv_y"]), int(p["pu_x"]), int(p["pu_y"])
+            ref, ss = fr[2], fr[2].shape[1]
+            o = (M + py + (qy >> 2)) * ss + M + px + (qx >> 2)
+            pred = np.zeros((h, w), dtype=dt)
+            if not (qx & 3) and not (qy & 3):
+                pred[:] = ref[M + py + (qy >> 2):M + py + (qy >> 2) + h, M + px + (qx >> 2):M + px + (qx >> 2) + w]
+            elif not (qy & 3):
+                oracle.ipfilter(0, ref, o, ss, pred, 0, w, w, h, qx & 3, depth, bits // 8)
+            elif not (qx & 3):
+                oracle.ipfilter(1, ref, o, ss, pred, 0, w, w, h, qy & 3, depth, bits // 8)
+            else:
+                tmp = np.zeros((h + 7, w), dtype=np.int16)
+                oracle.ipfilter(2, ref, o - 3 * ss, ss, tmp, 0, w, w, h + 7, qx & 3, depth, bits // 8)
+                oracle.ipfilter(3, tmp, 3 * w, w, pred, 0, w, w, h, qy & 3, depth, bits // 8)
+            org = fr[0][M + py:M + py + h, M + px:M + px + w].astype(np.int32)
+            host_dst[M + py:M + py + h, M + px:M + px + w] = np.clip(2 * org - pred.astype(np.int32), 0, (1 << depth) - 1).astype(dt)
+        all_jobs.append(J.make_jobs(W, H, gx, gy, w, h, method=J.BIPRED, subme=0, merange=4, qp=30, qmvp=(3, -5)))
+    got_plane = eng.download_plane(dst, fr[0].shape, dt)
+    assert np.array_equal(got_plane[M:M + H, M:M + W], host_dst[M:M + H, M:M + W])
+    jobs = np.concatenate(all_jobs)
+    host_dst_padded = synth.pad_plane(host_dst[M:M + H, M:M + W].astype(np.int32), depth)
+    # (the device plane's margins were never written: keep the searches' PUs inside the picture, as they are)
+    got = eng.search(dst, [ids[1]], jobs)
+    exp, _ = oracle.search(host_dst_padded, [fr[1]], jobs, threads=4, bit_depth=depth)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:5]
+    for i in ids + [dst]:
+        eng.release_plane(i)
+
+
+def api_mc_dtype():
+    from x265_amd.api import MC_PAIR_DTYPE
+    return MC_PAIR_DTYPE
+
+
+@pytest.mark.parametrize("bits", [8, 16])
 def test_rowwise_published_plane_equals_whole_upload(eng, oracle, bits):
     """a reference plane filled CTU row by CTU row from an unpadded picture, borders extended on the
     device, equals the plane uploaded whole with host-made borders - bytes and search results"""

@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.x265amd_lookahead_results_device.restype = vp
     L.x265amd_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_mc_cost_batch.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    L.x265amd_bipred_source_batch.argtypes = [vp, ci, ci, ci, ci, vp]
     L.x265amd_me_search_batch.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_me_search_batch_device_noalloc.argtypes = [vp, ci, cip, ci, vp, ci, vp]
@@ -316,6 +317,11 @@ class Engine:
         return out
 
     # -- search -------------------------------------------------------------------------------
+    def bipred_source_batch(self, dst_plane: int, w: int, h: int, pairs: np.ndarray):
+        """dst_plane[PU] = clip(2 * enc[PU] - motion-compensated prediction of the PU from ref at the q-pel MV); asynchronous"""
+        pairs = np.ascontiguousarray(pairs, dtype=MC_PAIR_DTYPE)
+        self._chk(self.lib.x265amd_bipred_source_batch(self.h, dst_plane, w, h, len(pairs), pairs.ctypes.data))
+
     def search(self, enc_plane: int, ref_planes, jobs: np.ndarray) -> np.ndarray:
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         refs = (C.c_int * len(ref_planes))(*ref_planes)

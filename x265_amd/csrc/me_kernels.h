@@ -187,6 +187,91 @@ __global__ void __launch_bounds__(64) k_mc_cost(const PlaneDesc *planes, int kin
 }
 
 // ------------------------------------------------------------------------------------------
+// The source block of a bidirectional-refinement search, made on the device: dst = ClipY(2 * org - pred) over the PU
+// (TComYuv::removeHighFreq, Lib/TLibCommon/TComYuv.cpp:673-702, luma part), pred = the other list's motion-compensated
+// prediction of the PU at its q-pel MV (TComPrediction::xPredInterLumaBlk, Lib/TLibCommon/TComPrediction.cpp:464-496; the
+// same four filter primitives as subpelCompare).  One thread per 4 adjacent pixels; reads of the reference are clamped
+// into its allocation like every other read of the library.
+template <typename PIX>
+__global__ void __launch_bounds__(256) k_bipred_src(const PlaneDesc *planes, int dst_plane, int w, int h,
+                                                   const x265amd_mc_pair *pairs, int n)
+{
+    typedef Dev<JobLds<PIX, 1, 64>> D;
+    constexpr int DW = D::DW;
+    const int ngx = w >> 2, G = ngx * h;
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (t >= n * G)
+        return;
+    const int item = t / G, g = t - item * G, y = g / ngx, x = (g - y * ngx) * 4;
+    const x265amd_mc_pair &p = pairs[item];
+    const PlaneDesc &org = planes[p.enc_plane], &ref = planes[p.ref_plane], &dst = planes[dst_plane];
+    const int qx = XA_S16(p.qmv_x), qy = XA_S16(p.qmv_y), xf = qx & 3, yf = qy & 3;
+    const int depth = DW == 1 ? 8 : ref.depth, maxval = (1 << depth) - 1;
+    const int64_t lo = ref.lo, hi = ref.hi;
+    const PIX *r0 = (const PIX*)ref.origin;
+    const int64_t off = (int64_t)(p.pu_y + y + (qy >> 2)) * ref.stride + p.pu_x + x + (qx >> 2);
+    auto clampo = [&](int64_t o, int len) { o = o < lo ? lo : o; return o > hi - len ? hi - len : o; };
+    auto rd4 = [&](int64_t o, uint32_t *r) {
+        const PIX *q = r0 + clampo(o, 4);
+        r[0] = ld_u32(q);
+        r[1] = DW == 2 ? ld_u32((const uint8_t*)q + 4) : 0;
+    };
+    auto rd12 = [&](int64_t o, uint32_t *r) {
+        const PIX *q = r0 + clampo(o, 12);
+#pragma unroll
+        for (int i = 0; i < 3 * DW; i++)
+            r[i] = ld_u32((const uint8_t*)q + 4 * i);
+    };
+    int pred[4];
+    if (!xf && !yf)
+    {
+        uint32_t d[2];
+        rd4(off, d);
+        const P4 v = D::unpack4(d);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            pred[i] = v.v[i];
+    }
+    else if (!yf)
+    {
+        uint32_t px[6];
+        rd12(off - 3, px);
+        D::h_pp(px, xf, depth, pred);
+    }
+    else if (!xf)
+    {
+        uint32_t rw[8][2];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            rd4(off + (int64_t)(k - 3) * ref.stride, rw[k]);
+        D::v_pp(rw, yf, depth, pred);
+    }
+    else
+    {
+        uint32_t im[8][2];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            uint32_t px[6];
+            rd12(off + (int64_t)(k - 3) * ref.stride - 3, px);
+            int sm[4];
+            D::h_ps(px, xf, depth, sm);
+            im[k][0] = __builtin_amdgcn_perm((uint32_t)sm[1], (uint32_t)sm[0], 0x05040100);
+            im[k][1] = __builtin_amdgcn_perm((uint32_t)sm[3], (uint32_t)sm[2], 0x05040100);
+        }
+        D::v_sp(im, yf, depth, pred);
+    }
+    const PIX *o = (const PIX*)org.origin + (int64_t)(p.pu_y + y) * org.stride + p.pu_x + x;
+    PIX *d = (PIX*)const_cast<void*>(dst.origin) + (int64_t)(p.pu_y + y) * dst.stride + p.pu_x + x;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int v = 2 * (int)o[i] - pred[i];
+        d[i] = (PIX)(v < 0 ? 0 : v > maxval ? maxval : v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The four 8-tap luma filter primitives on their own (common/primitives.h:186-188, 263-265;
 // common/ipfilter.cpp:38-139, 265-309, 354-425), through the same device functions the search's
 // prediction code uses.  kind 0 = ipfilter_pp[H_8], 1 = ipfilter_pp[V_8], 2 = ipfilter_ps[H_8]

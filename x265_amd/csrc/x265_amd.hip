@@ -2108,6 +2108,48 @@ int x265amd_mc_cost_batch(x265amd_ctx *c, int kind, int w, int h, int n, const x
     return 0;
 }
 
+int x265amd_bipred_source_batch(x265amd_ctx *c, int dst_plane, int w, int h, int n, const x265amd_mc_pair *pairs)
+{
+    if (!c || !pairs || n < 0)
+        return X265AMD_ERR_INVALID;
+    if (n == 0)
+        return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!valid_dim(w) || !valid_dim(h) || dst_plane < 0 || dst_plane >= MAX_PLANES || !c->used[dst_plane] || c->h_planes[dst_plane].lr_step)
+        return fail(c, X265AMD_ERR_INVALID, "bad block size or destination plane");
+    const PlaneDesc &d = c->h_planes[dst_plane];
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_mc_pair &p = pairs[i];
+        if (p.enc_plane < 0 || p.enc_plane >= MAX_PLANES || !c->used[p.enc_plane] ||
+            p.ref_plane < 0 || p.ref_plane >= MAX_PLANES || !c->used[p.ref_plane])
+            return fail(c, X265AMD_ERR_INVALID, "pair names an unregistered plane");
+        const PlaneDesc &e = c->h_planes[p.enc_plane], &r = c->h_planes[p.ref_plane];
+        if (e.bpp != r.bpp || e.bpp != d.bpp || r.lr_step || e.lr_step)
+            return fail(c, X265AMD_ERR_INVALID, "mixed pixel sizes, or a half-resolution plane");
+        if (p.qmv_x < -32768 || p.qmv_x > 32767 || p.qmv_y < -32768 || p.qmv_y > 32767)
+            return fail(c, X265AMD_ERR_INVALID, "MV does not fit 16 bits");
+        const int rx = p.pu_x + (p.qmv_x >> 2), ry = p.pu_y + (p.qmv_y >> 2);
+        if (p.pu_x < -e.margin_x || p.pu_y < -e.margin_y || p.pu_x + w > e.width + e.margin_x || p.pu_y + h > e.height + e.margin_y ||
+            p.pu_x < -d.margin_x || p.pu_y < -d.margin_y || p.pu_x + w > d.width + d.margin_x || p.pu_y + h > d.height + d.margin_y ||
+            rx - 3 < -r.margin_x || ry - 3 < -r.margin_y || rx + w + 4 > r.width + r.margin_x || ry + h + 4 > r.height + r.margin_y)
+            return fail(c, X265AMD_ERR_RANGE, "block (with the filter apron) outside a padded plane");
+    }
+    if (int rc = sync_planes(c)) return rc;
+    if (int rc = ensure(c, c->pairs, (size_t)n * sizeof(x265amd_mc_pair))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, pairs, (size_t)n * sizeof(x265amd_mc_pair), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (pairs is borrowed only during the call)
+    const long long threads = (long long)n * (w >> 2) * h;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (d.bpp == 1)
+        hipLaunchKernelGGL(k_bipred_src<uint8_t>, grid, block, 0, c->stream, c->d_planes, dst_plane, w, h, (const x265amd_mc_pair*)c->pairs.p, n);
+    else
+        hipLaunchKernelGGL(k_bipred_src<uint16_t>, grid, block, 0, c->stream, c->d_planes, dst_plane, w, h, (const x265amd_mc_pair*)c->pairs.p, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 static int validate_jobs(x265amd_ctx *c, const x265amd_me_job *jobs, int n, int n_refs, bool *any_full)
 {
     *any_full = false;
