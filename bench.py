@@ -539,6 +539,9 @@ def main():
                                                      "host_queue_frac_of_step": host_queue[0] / (cdt / 20 * 1e6),
                                                      "note": "the headline step with a reference broadcast in it (one-rank RCCL group): ring acquire / "
                                                              "release, the collective, the list's launches; host_queue = the host's time to queue a step"}
+            # (the single-GPU legs below run without a collective in their steps, as `value` did)
+            ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, collective=False)
+            step_no[0] = 0
     if not args.only_primary:
         try:
             line["sharded"] = sharded_legs(eng, dev, rank, world, args, barrier, dist if (world > 1 or dist.is_initialized()) else None)
@@ -661,6 +664,17 @@ def main():
                          "frame_pairs_per_s": LOOK_PAIRS / (look[LOOK_PAIRS][0] * 1e-3),
                          "value": look[LOOK_PAIRS][1] / (look[LOOK_PAIRS][0] * 1e-3), "unit": "evals/s",
                          "single_pair_kernel_ms": look[1][0], "lowres_init_us_per_picture": lowres_us}
+
+    # ---- the HEX leg again with its launches ordered by the lookahead's field of THIS frame pair (computed above from the
+    # half-resolution planes, as an encoder's lookahead does before the frame is encoded): the jobs the field predicts to be
+    # long start first.  Not `value`, and not the order learnt from a previous run of the same frame.
+    jl_hex.order_by_field(look_field, look_cw, look_ch)
+    odt, _, _, k_ord_ms = timed(jl_hex, 2, args.steps)
+    ord_res = jl_hex.run(enc_id, [ref_id], fetch=True)
+    line["hex_search"]["lookahead_ordered"] = {"ms_per_frame": odt / args.steps * 1e3, "kernel_ms": k_ord_ms,
+                                               "results_equal": bool(np.array_equal(ord_res, hex_res)),
+                                               "note": "launch order from x265amd_lookahead_me's half-resolution field of the same frame pair "
+                                                       "(x265amd_joblist_order_by_field); the lookahead's own time is in `lookahead`"}
 
     # ---- 4K 10-bit, Hadamard integer stage (BASELINE configs[4]'s metric): exhaustive +-16 SA8D search of every
     # square PU 64/32/16/8 in one list; the candidate-per-lane kernel prices the 8x8 cells once for all four levels

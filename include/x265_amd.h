@@ -291,6 +291,13 @@ int x265amd_joblist_results_async(x265amd_ctx *ctx, x265amd_joblist *list, x265a
  * consecutive frames move alike).  Blocks until the last run has finished.  No counterpart in the
  * reference, whose CTU rows are load-balanced by its thread pool (common/threadpool.cpp). */
 int x265amd_joblist_rebalance(x265amd_ctx *ctx, x265amd_joblist *list);
+/* The same reordering for a NEW picture, from the lookahead's half-resolution motion field of that picture
+ * (x265amd_lookahead_me's output for the (picture, reference) pair; cu_w x cu_h entries, host memory): a
+ * pattern search is long when the block moved far from its predictor, and the field says how far
+ * (2 x the half-resolution MV against the job's qmvp).  Results do not depend on the order.  In the
+ * reference the lookahead runs ahead of the encode for its own reasons (encoder/slicetype.cpp); its field
+ * is free information for the scheduler here.  Blocks until the list is idle. */
+int x265amd_joblist_order_by_field(x265amd_ctx *ctx, x265amd_joblist *list, const x265amd_me_result *field, int cu_w, int cu_h);
 int x265amd_joblist_destroy(x265amd_ctx *ctx, x265amd_joblist *list);
 
 /* ---- lookahead: whole-frame motion search ------------------------------------------------

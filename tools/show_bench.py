@@ -9,6 +9,8 @@ print("value %.4g %s  ms_per_step %.4f  exhaustive kernels %.4f ms (frac %.3f, e
 if "hex_search" in d:
     h = d["hex_search"]
     print("hex: %.4g evals/s  ms/frame %.4f  k_search %.4f ms  valu frac %.4f" % (h["value"], h["ms_per_frame"], h["roofline"]["kernel_ms"], h["roofline"]["frac"]))
+    if "lookahead_ordered" in h:
+        print("  hex ordered by the lookahead field: ms/frame %.4f  k_search %.4f ms  equal %s" % (h["lookahead_ordered"]["ms_per_frame"], h["lookahead_ordered"]["kernel_ms"], h["lookahead_ordered"]["results_equal"]))
     print("dia: %.4g evals/s  ms/frame %.4f" % (d["dia_search"]["value"], d["dia_search"]["ms_per_frame"]))
     p = d["pcie_inclusive"]
     print("pcie-inclusive ms/frame: full %.4f  hex %.4f" % (p["full_search"]["ms_per_frame"], p["hex_search"]["ms_per_frame"]))

@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     L.x265amd_joblist_results_device.restype = vp
     L.x265amd_joblist_results.argtypes = [vp, vp, vp]
     L.x265amd_joblist_results_async.argtypes = [vp, vp, vp]
+    L.x265amd_joblist_order_by_field.argtypes = [vp, vp, vp, ci, ci]
     L.x265amd_plane_refill_async.argtypes = [vp, C.c_int, vp]
     L.x265amd_build_info.argtypes = []
     L.x265amd_build_info.restype = C.c_char_p
@@ -394,6 +395,12 @@ class JobList:
     def results_async(self, out_ptr: int):
         """queue the copy of the last run's results to page-locked host memory at `out_ptr` (n * 8 bytes); no wait"""
         self.eng._chk(self.eng.lib.x265amd_joblist_results_async(self.eng.h, self.h, out_ptr))
+
+    def order_by_field(self, field: np.ndarray, cu_w: int, cu_h: int):
+        """start first the jobs the lookahead's half-resolution field (cu_w x cu_h results) predicts to be long"""
+        field = np.ascontiguousarray(field, dtype=RESULT_DTYPE)
+        assert field.size == cu_w * cu_h
+        self.eng._chk(self.eng.lib.x265amd_joblist_order_by_field(self.eng.h, self.h, field.ctypes.data, cu_w, cu_h))
 
     def rebalance(self):
         """start the jobs that were longest in the last run first in the following runs"""

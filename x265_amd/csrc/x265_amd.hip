@@ -2364,6 +2364,54 @@ int x265amd_joblist_results(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_resul
     return 0;
 }
 
+namespace {
+// reorder every class of a list: 8 groups by predicted length, longest first; inside a group the planned (picture / XCD
+// band) order stays
+int order_by_length(x265amd_ctx *c, x265amd_joblist *L, const std::vector<unsigned> &len)
+{
+    int off = 0;
+    for (int cls = 0; cls < JOB_CLASSES; cls++)
+    {
+        const int cnt = L->cls_count[cls];
+        if (cnt > 1)
+        {
+            unsigned mx = 1;
+            for (int i = 0; i < cnt; i++)
+                mx = std::max(mx, len[L->order[off + i]]);
+            auto group = [&](int id) { return 7 - (int)((uint64_t)len[id] * 8 / ((uint64_t)mx + 1)); };
+            std::stable_sort(L->order.begin() + off, L->order.begin() + off + cnt,
+                             [&](int a, int b) { return group(a) < group(b); });
+        }
+        off += cnt;
+    }
+    HIPCHK(c, hipMemcpy(L->idx.p, L->order.data(), (size_t)L->n * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+} // namespace
+
+int x265amd_joblist_order_by_field(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_result *field, int cu_w, int cu_h)
+{
+    if (!c || !L || !field || cu_w <= 0 || cu_h <= 0)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (L->h_jobs.empty())
+        return fail(c, X265AMD_ERR_INVALID, "the list keeps no host copy of its jobs");
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // the index list may be in use
+    // a pattern search walks from its predictor to where the block went: its length grows with the distance between the
+    // two.  The half-resolution field says where the block went (its MVs are q-pel of the half-resolution picture: x 2).
+    std::vector<unsigned> len(L->n);
+    for (int i = 0; i < L->n; i++)
+    {
+        const x265amd_me_job &j = L->h_jobs[i];
+        const int cx = std::min(cu_w - 1, std::max(0, (j.pu_x + j.w / 2) >> 4)), cy = std::min(cu_h - 1, std::max(0, (j.pu_y + j.h / 2) >> 4));
+        const x265amd_me_result &f = field[cx + (size_t)cy * cu_w];
+        const int dx = 2 * f.mvx - j.qmvp_x, dy = 2 * f.mvy - j.qmvp_y;
+        len[i] = (unsigned)(std::abs(dx) + std::abs(dy));
+    }
+    return order_by_length(c, L, len);
+}
+
 int x265amd_joblist_results_async(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_result *out)
 {
     if (!c || !L || !out)
@@ -2422,24 +2470,7 @@ int x265amd_joblist_rebalance(x265amd_ctx *c, x265amd_joblist *L)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<unsigned> hist(L->n);
     HIPCHK(c, hipMemcpy(hist.data(), L->hist.p, (size_t)L->n * sizeof(unsigned), hipMemcpyDeviceToHost));
-    int off = 0;
-    for (int cls = 0; cls < JOB_CLASSES; cls++)
-    {
-        const int cnt = L->cls_count[cls];
-        if (cnt > 1)
-        {
-            unsigned mx = 1;
-            for (int i = 0; i < cnt; i++)
-                mx = std::max(mx, hist[L->order[off + i]]);
-            // 8 length groups, longest first; inside a group the planned (picture / XCD band) order stays
-            auto group = [&](int id) { return 7 - (int)((uint64_t)hist[id] * 8 / ((uint64_t)mx + 1)); };
-            std::stable_sort(L->order.begin() + off, L->order.begin() + off + cnt,
-                             [&](int a, int b) { return group(a) < group(b); });
-        }
-        off += cnt;
-    }
-    HIPCHK(c, hipMemcpy(L->idx.p, L->order.data(), (size_t)L->n * sizeof(int), hipMemcpyHostToDevice));
-    return 0;
+    return order_by_length(c, L, hist);
 }
 
 int x265amd_joblist_destroy(x265amd_ctx *c, x265amd_joblist *L)

@@ -107,7 +107,7 @@ class PlaneRing:
 
     On the CPU (gloo tests) the collective is synchronous and there is nothing to order."""
 
-    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = False):
+    def __init__(self, buffers, engine=None, src: int = 0, overlap: bool = False, collective=None):
         assert len(buffers) == 2
         self.buffers = list(buffers)
         self.engine = engine
@@ -115,7 +115,8 @@ class PlaneRing:
         self.overlap = overlap
         self.gpu = engine is not None and self.buffers[0].is_cuda
         self.ready = -1                     # index of the newest plane already broadcast
-        self.collective = dist.is_available() and dist.is_initialized()
+        # (collective=False: hand out buffers without broadcasting although a process group exists)
+        self.collective = (dist.is_available() and dist.is_initialized()) if collective is None else bool(collective)
         self.free = [None, None]            # per buffer: event behind the last search that read it
         self.filled = [None, None]          # per buffer: event behind the broadcast that filled it
         if self.gpu:
