@@ -291,6 +291,10 @@ int x265amd_joblist_results_async(x265amd_ctx *ctx, x265amd_joblist *list, x265a
  * consecutive frames move alike).  Blocks until the last run has finished.  No counterpart in the
  * reference, whose CTU rows are load-balanced by its thread pool (common/threadpool.cpp). */
 int x265amd_joblist_rebalance(x265amd_ctx *ctx, x265amd_joblist *list);
+/* out[i] = block-cost evaluations job i took in the list's last run (waits for it) */
+int x265amd_joblist_eval_counts(x265amd_ctx *ctx, x265amd_joblist *list, uint32_t *out);
+/* the same reordering from lengths the caller predicts: length[i] for job i, any unit (8 groups, longest first) */
+int x265amd_joblist_order_by_length(x265amd_ctx *ctx, x265amd_joblist *list, const uint32_t *length);
 /* The same reordering for a NEW picture, from the lookahead's half-resolution motion field of that picture
  * (x265amd_lookahead_me's output for the (picture, reference) pair; cu_w x cu_h entries, host memory): a
  * pattern search is long when the block moved far from its predictor, and the field says how far

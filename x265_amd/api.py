@@ -105,6 +105,8 @@ def load_library() -> C.CDLL:
     L.x265amd_joblist_results.argtypes = [vp, vp, vp]
     L.x265amd_joblist_results_async.argtypes = [vp, vp, vp]
     L.x265amd_joblist_order_by_field.argtypes = [vp, vp, vp, ci, ci]
+    L.x265amd_joblist_eval_counts.argtypes = [vp, vp, vp]
+    L.x265amd_joblist_order_by_length.argtypes = [vp, vp, vp]
     L.x265amd_plane_refill_async.argtypes = [vp, C.c_int, vp]
     L.x265amd_build_info.argtypes = []
     L.x265amd_build_info.restype = C.c_char_p
@@ -401,6 +403,18 @@ class JobList:
         field = np.ascontiguousarray(field, dtype=RESULT_DTYPE)
         assert field.size == cu_w * cu_h
         self.eng._chk(self.eng.lib.x265amd_joblist_order_by_field(self.eng.h, self.h, field.ctypes.data, cu_w, cu_h))
+
+    def eval_counts(self) -> np.ndarray:
+        """block-cost evaluations per job of the last run"""
+        out = np.zeros(self.n, dtype=np.uint32)
+        self.eng._chk(self.eng.lib.x265amd_joblist_eval_counts(self.eng.h, self.h, out.ctypes.data))
+        return out
+
+    def order_by_length(self, length: np.ndarray):
+        """start first the jobs with the largest predicted length (one value per job)"""
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        assert length.size == self.n
+        self.eng._chk(self.eng.lib.x265amd_joblist_order_by_length(self.eng.h, self.h, length.ctypes.data))
 
     def rebalance(self):
         """start the jobs that were longest in the last run first in the following runs"""

@@ -2389,6 +2389,29 @@ int order_by_length(x265amd_ctx *c, x265amd_joblist *L, const std::vector<unsign
 }
 } // namespace
 
+int x265amd_joblist_eval_counts(x265amd_ctx *c, x265amd_joblist *L, uint32_t *out)
+{
+    if (!c || !L || !out)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!L->ran || !L->keep_hist)
+        return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, L->hist.p, (size_t)L->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int x265amd_joblist_order_by_length(x265amd_ctx *c, x265amd_joblist *L, const uint32_t *length)
+{
+    if (!c || !L || !length)
+        return X265AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // the index list may be in use
+    return order_by_length(c, L, std::vector<unsigned>(length, length + L->n));
+}
+
 int x265amd_joblist_order_by_field(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_result *field, int cu_w, int cu_h)
 {
     if (!c || !L || !field || cu_w <= 0 || cu_h <= 0)
