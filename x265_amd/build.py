@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "x265_amd.hip")
 PART = os.path.join(HERE, "csrc", "x265_amd_part.hip")
-N_PARTS = 6
+N_PARTS = 7
 OUT = os.environ.get("X265AMD_OUT", os.path.join(HERE, "libx265amd.so"))
 PUBLIC_H = os.path.join(os.path.dirname(HERE), "include", "x265_amd.h")
 # headers the instantiation units (x265_amd_part.hip) include, and those only the main unit includes

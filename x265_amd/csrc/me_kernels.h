@@ -19,7 +19,7 @@ struct BatchParams
     unsigned        *hist;                // optional: evaluations spent on job i, written to hist[i]
     const unsigned char *fb_jobs;         // optional: fb_jobs[i] != 0 = an exhaustive kernel ran job i's integer stage
                                           // (without it: exactly the jobs full_kernel_eligible accepts)
-    int32_t          lane_on;             // the smallest PUs run one job per QUAD of lanes (k_lane, me_lane.h), not in k_search
+    int32_t          lane_on;             // the kernels of me_lane.h take the jobs group_job_class names (0: none), not k_search
 };
 
 // The field checks every entry path applies to a job: the host entry points refuse a batch that fails them
@@ -70,24 +70,29 @@ __device__ __host__ inline bool had_kernel_eligible(const J &j, int bpp)
 // throughput wants the registers and wavefront slots a large PU's waiting workers hold; eight
 // alone).  `idx` (optional) lists the jobs of this launch; without it every job is visited and
 // those of the other classes are skipped.
-constexpr int JOB_CLASSES = 4;           // 0 .. 2: the general kernel's classes; LANE_CLASS: the quad-per-job kernel's jobs
-constexpr int LANE_CLASS = 3;
+constexpr int JOB_CLASSES = 5;           // 0 .. 2: the general kernel's classes; LANE_CLASS / ROW_CLASS: the quad- / row-per-job kernel's jobs
+constexpr int LANE_CLASS = 3, ROW_CLASS = 4;
 constexpr int LANE_MAX_AREA = 64;        // PU pixels of a quad-per-job search (four 4x4 tiles): 8x8, 8x4, 4x8, 16x4, 4x16, 4x4, 12x4, 4x12
+constexpr int ROW_MAX_AREA = 1024;       // PU pixels of a row-per-job search: what is left of a FULL job whose scan an exhaustive kernel ran (off by default)
 constexpr int EVAL_SLOTS = 256;          // evaluation counters (summed on read-out)
 __device__ __host__ inline int job_class(int w, int h) { return w * h <= 256 ? 0 : w * h <= 1024 ? 1 : 2; }
-constexpr int LANE_FULL_MAX_AREA = 64;   // ... and of a FULL job whose scan an exhaustive kernel ran (only a handful of evaluations are left of it).
-                                         // Measured on MI355X: beyond four tiles the quad's chain of tile steps (one memory round trip each) is longer
-                                         // than the general kernel's work - 16x16: 0.033 vs 0.026 ms per 1080p frame, 32x32: 0.095 vs 0.026 - so the
-                                         // default keeps those there (X265AMD_LANE_FULL raises it, up to 1024)
-// Is this job one for the quad-per-job kernel?  `lane_on`: 0 = no (a reference of the batch is a half-resolution set),
-// else the largest PU area it takes of FULL-search jobs whose scan ran in an exhaustive kernel (`covered`); any search
-// of a PU of at most LANE_MAX_AREA pixels goes there.
+// Which of the kernels of me_lane.h takes this job, if any: LANE_CLASS (four lanes per job): any search of a PU of at most
+// LANE_MAX_AREA pixels; ROW_CLASS (sixteen lanes per job): a FULL job of a PU of at most `lane_on` pixels whose scan ran
+// in an exhaustive kernel (`covered`): only the predictor checks, the slab combine and the sub-pel rounds are left of it.
+// `lane_on`: 0 = neither (a reference of the batch is a half-resolution set), else the row class's largest area (at
+// least LANE_MAX_AREA, which switches that class off).  Returns -1 for a job of the general kernel.
 template <class J>
-__device__ __host__ inline bool lane_job(const J &j, bool covered, int lane_on)
+__device__ __host__ inline int group_job_class(const J &j, bool covered, int lane_on)
 {
     const int area = j.w * j.h;
-    return lane_on && (area <= LANE_MAX_AREA || (covered && j.method == X265AMD_FULL && area <= lane_on));
+    if (!lane_on)
+        return -1;
+    if (area <= LANE_MAX_AREA)
+        return LANE_CLASS;
+    return (covered && j.method == X265AMD_FULL && area <= lane_on) ? ROW_CLASS : -1;
 }
+template <class J>
+__device__ __host__ inline bool lane_job(const J &j, bool covered, int lane_on) { return group_job_class(j, covered, lane_on) >= 0; }
 
 template <class L>
 __global__ void __launch_bounds__(L::NT) __attribute__((amdgpu_waves_per_eu(L::NW == 1 && L::INL ? 8 : 1))) k_search(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n, int cls,

@@ -21,6 +21,10 @@
 // Every 4- or 12-pixel read is clamped into the plane allocation exactly like the general kernel's reads
 // (Dev<>::Src), so the two kernels agree bit for bit on every job, in-margin or not.
 //
+// The same code with SIXTEEN lanes per job (LPJ = 16: one 16x16 block of tiles per step, four jobs per wavefront) takes
+// the PUs of up to 32x32 pixels whose exhaustive scan ran in its own kernel: what is left of such a job is a handful of
+// evaluations, for which a wavefront per job spends most of its instructions on set-up.
+//
 // Neighbouring quads hold neighbouring PUs (the planner orders this class by shape, search kind and picture
 // position), so a wavefront's row reads fall into a few cache lines and its quads mostly run the same loops.
 #pragma once
@@ -66,11 +70,12 @@ constexpr uint64_t nib_range_mul()
 }
 typedef int P8 __attribute__((ext_vector_type(8)));     // eight values in registers (a struct would travel through the stack)
 
-template <typename PIX>
+template <typename PIX, int LPJ = 4>      // LPJ: lanes per job, 4 or 16
 struct QuadWave
 {
     typedef Dev<JobLds<PIX, 1, 64>> D;
     static constexpr int DW = D::DW;
+    static_assert(LPJ == 4 || LPJ == 16, "a job is a quad or a 16-lane row of lanes");
 
     // the job, identical in the four lanes of its quad
     const PIX *enc;                 // the PU's first pixel in the encoder plane
@@ -118,6 +123,17 @@ struct QuadWave
         v += dpp<0x4E>(v);          // quad_perm [2,3,0,1]
         return v;
     }
+    // sum over the job's lanes, result in all of them
+    static __device__ __forceinline__ int job_sum(int v)
+    {
+        v = quad_sum(v);
+        if (LPJ == 16)
+        {
+            v += xor4(v);
+            v += xor8(v);
+        }
+        return v;
+    }
     static __device__ __forceinline__ int clamp_off(int o, int len, int gLo, int gHi)
     {
         o = o < gLo ? gLo : o;
@@ -142,40 +158,42 @@ struct QuadWave
         return (cflags & CF_NOTRUNC) ? a + b : ((a + b) & 0xffff);
     }
 
-    // The PU's 4x4 tiles are dealt to the quad's lanes in `tile_steps` steps of four tiles.  PUs whose sides are multiples
-    // of 8: step i is 8x8 block i, lane t takes its quadrant t (so the 8x8 transform's last stage stays inside the quad);
-    // sides multiples of 16: the blocks of one 16x16 block come in four consecutive steps (sa8d_inter rounds per 16x16
-    // there, common/pixel.cpp:347-362).  Any other PU: tile 4 i + t in raster order, `on` = the tile exists (a lane
-    // without one repeats tile 0 and adds nothing).
+    // The PU's 4x4 tiles are dealt to the job's lanes in `tile_steps` steps of LPJ tiles.  PUs whose sides are multiples
+    // of 8: a quad of lanes takes one 8x8 block per step, lane q of the quad its quadrant q (so the 8x8 transform's last
+    // stage stays inside the quad); sides multiples of 16: the four blocks of a 16x16 block are consecutive (sa8d_inter
+    // rounds per 16x16 there, common/pixel.cpp:347-362: four steps of a quad, or one step of a 16-lane row).  Any other
+    // PU: tiles in raster order.  `on` = the lane has a tile in this step (one without repeats tile 0 and adds nothing).
     static __device__ __forceinline__ int tile_steps(int w, int h)
     {
-        return ((w | h) & 7) ? (((w * h) >> 4) + 3) >> 2 : (w * h) >> 6;
+        return ((w | h) & 7) ? (((w * h) >> 4) + LPJ - 1) / LPJ : (((w * h) >> 6) + LPJ / 4 - 1) / (LPJ / 4);
     }
     static __device__ __forceinline__ void tile_at(int i, int w, int h, int &tx, int &ty, bool &on)
     {
-        const int t = (int)(threadIdx.x & 3);
+        const int t = (int)(threadIdx.x & (LPJ - 1));
         if (((w | h) & 7) == 0)
         {
+            const int b0 = i * (LPJ / 4) + (t >> 2);
+            on = b0 < ((w * h) >> 6);
+            const int b = on ? b0 : 0;
             int bx, by;
             if (((w | h) & 15) == 0)
             {
-                const int g = i >> 2, q = i & 3, ngx = w >> 4, gy = g / ngx, gx = g - gy * ngx;
+                const int g = b >> 2, q = b & 3, ngx = w >> 4, gy = g / ngx, gx = g - gy * ngx;
                 bx = gx * 2 + (q & 1);
                 by = gy * 2 + (q >> 1);
             }
             else
             {
                 const int nbx = w >> 3;
-                by = i / nbx;
-                bx = i - by * nbx;
+                by = b / nbx;
+                bx = b - by * nbx;
             }
             tx = bx * 8 + (t & 1) * 4;
-            ty = by * 8 + (t >> 1) * 4;
-            on = true;
+            ty = by * 8 + ((t >> 1) & 1) * 4;
         }
         else
         {
-            const int ntx = w >> 2, tt = 4 * i + t;
+            const int ntx = w >> 2, tt = LPJ * i + t;
             on = tt < ((w * h) >> 4);
             const int u = on ? tt : 0;
             ty = u / ntx;
@@ -235,7 +253,7 @@ struct QuadWave
         P8 out = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
         for (int k = 0; k < NB; k++)
-            out[k] = quad_sum((int)s[k]) + mv[k];
+            out[k] = job_sum((int)s[k]) + mv[k];
         return out;
     }
 
@@ -268,7 +286,10 @@ struct QuadWave
         const int off0 = (qy >> 2) * stride + (qx >> 2);
         const int mv = (cflags & CF_NOMV) ? 0 : mv_cost(cost, mvp, label, cflags);
         const int am = D::accum_mode(kind, w, h), steps = tile_steps(w, h);
-        int acc = 0, tot = 0;                   // acc: magnitudes not yet rounded (am 3: of the running 16x16 block)
+        // acc: the lane's magnitudes not yet rounded; tot: rounded sums, kept by ONE lane of the rounding unit (a quad for
+        // sa8d8's 8x8 blocks, the quad over four steps or the 16-lane row for sa8d16's 16x16 blocks)
+        const int t = (int)(threadIdx.x & (LPJ - 1));
+        int acc = 0, tot = 0;
         for (int i = 0; i < steps; i++)
         {
             int tx, ty;
@@ -378,19 +399,23 @@ struct QuadWave
 #pragma unroll
                 for (int c = 0; c < 4; c++)
                     acc += d[y][c] < 0 ? -d[y][c] : d[y][c];
-            if (am == 2 || (am == 3 && (i & 3) == 3))
+            if (am == 2)
             {
-                tot += (quad_sum(acc) + 2) >> 2;            // sa8d8 rounds per 8x8, sa8d16 per 16x16
+                const int r = (quad_sum(acc) + 2) >> 2;     // sa8d8: one rounding per 8x8 block
+                tot += (t & 3) == 0 && on ? r : 0;
+                acc = 0;
+            }
+            else if (am == 3 && (LPJ == 16 || (i & 3) == 3))
+            {
+                const int r = (job_sum(acc) + 2) >> 2;      // sa8d16: one rounding per 16x16 block
+                tot += t == 0 ? r : 0;
                 acc = 0;
             }
         }
-        if (am <= 1)
-        {
-            tot = quad_sum(acc);
-            if (am == 1)
-                tot >>= 1;                                  // every 4x4 sum of magnitudes is even
-        }
-        return tot + mv;
+        int res = job_sum(am <= 1 ? acc : tot);
+        if (am == 1)
+            res >>= 1;                                      // every 4x4 sum of magnitudes is even
+        return res + mv;
     }
 
     __device__ __forceinline__ int cost_at(int qx, int qy, int lx, int ly, int kind, int cflags) const
@@ -462,16 +487,17 @@ struct QuadWave
             }
         }
     }
-    // winner over a job's slab partials: lowest cost, then lowest raster index (see combine_slabs).  Lane t of the quad
-    // reads slabs t, t + 4, ... (all loads in flight together); the quad's minimum goes to its four lanes.
+    // winner over a job's slab partials: lowest cost, then lowest raster index (see combine_slabs).  Lane t of the job
+    // reads slabs t, t + LPJ, ... (all loads in flight together); the minimum goes to all of the job's lanes.
     __device__ __forceinline__ SlabBest slab_best(const FullBest *fb, int n, int nxr, int minx, int miny) const
     {
-        const int t = (int)(threadIdx.x & 3);
-        FullBest f[4];
+        const int t = (int)(threadIdx.x & (LPJ - 1));
+        constexpr int PER = 16 / LPJ;
+        FullBest f[PER];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < PER; k++)
         {
-            const int s = t + 4 * k;
+            const int s = t + LPJ * k;
             f[k] = fb[s < n ? s : 0];
             if (s >= n)
                 f[k].cost = 0x7fffffff;
@@ -480,7 +506,7 @@ struct QuadWave
         uint32_t bc = 0x7fffffffu, bi = ~0u;
         int bm = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < PER; k++)
         {
             const uint32_t c = (uint32_t)f[k].cost, i = (uint32_t)((f[k].mvy - miny) * nxr + (f[k].mvx - minx));
             const bool better = f[k].cost != 0x7fffffff && (c < bc || (c == bc && i < bi));
@@ -489,11 +515,11 @@ struct QuadWave
             bm = better ? (((int)f[k].mvy << 16) | ((int)f[k].mvx & 0xffff)) : bm;
         }
 #pragma unroll
-        for (int step = 0; step < 2; step++)
+        for (int step = 0; step < (LPJ == 16 ? 4 : 2); step++)
         {
-            const uint32_t oc = (uint32_t)(step ? dpp<0x4E>((int)bc) : dpp<0xB1>((int)bc));
-            const uint32_t oi = (uint32_t)(step ? dpp<0x4E>((int)bi) : dpp<0xB1>((int)bi));
-            const int om = step ? dpp<0x4E>(bm) : dpp<0xB1>(bm);
+            auto xch = [&](int v) { return step == 0 ? dpp<0xB1>(v) : step == 1 ? dpp<0x4E>(v) : step == 2 ? xor4(v) : xor8(v); };
+            const uint32_t oc = (uint32_t)xch((int)bc), oi = (uint32_t)xch((int)bi);
+            const int om = xch(bm);
             const bool better = oc < bc || (oc == bc && oi < bi);
             bc = better ? oc : bc;
             bi = better ? oi : bi;
@@ -506,13 +532,14 @@ struct QuadWave
     }
 };
 
-// Sixteen jobs per wavefront: quad q of workgroup b takes job idx[16 b + q] (or job 16 b + q without an index list,
-// skipping the jobs of the general kernel's classes).
-template <typename PIX>
+// 64 / LPJ jobs per wavefront: lane group q of workgroup b takes job idx[(64 / LPJ) b + q] (or that job of the array
+// without an index list, skipping the jobs of the other classes).  LPJ = 4: the quad-per-job class (LANE_CLASS);
+// LPJ = 16: the row-per-job class (ROW_CLASS).
+template <typename PIX, int LPJ>
 __global__ void __launch_bounds__(64) k_lane(BatchParams P, const x265amd_me_job *jobs, const int *idx, int n,
                                              const FullBest *fb, int fb_stride, x265amd_me_result *out, unsigned long long *evals)
 {
-    const int slot = (int)(blockIdx.x * 16 + (threadIdx.x >> 2));
+    const int slot = (int)(blockIdx.x * (64 / LPJ) + threadIdx.x / LPJ);
     unsigned n_evals = 0;
     if (slot < n)
     {
@@ -521,17 +548,17 @@ __global__ void __launch_bounds__(64) k_lane(BatchParams P, const x265amd_me_job
         j.load(jobs + id);
         const bool valid = idx || job_fields_valid(j, P.n_refs);
         const bool covered = fb && (P.fb_jobs ? P.fb_jobs[id] != 0 : full_kernel_eligible(j, (int)sizeof(PIX)));
-        if (valid && (idx || lane_job(j, covered, P.lane_on)))
+        if (valid && (idx || group_job_class(j, covered, P.lane_on) == (LPJ == 4 ? LANE_CLASS : ROW_CLASS)))
         {
             const PlaneDesc &enc = P.planes[P.enc_plane];
             const PlaneDesc &ref = P.planes[P.ref_planes[j.ref_idx]];
-            QuadWave<PIX> W;
+            QuadWave<PIX, LPJ> W;
             W.bind(enc, ref, j.pu_x, j.pu_y, j.w, j.h, P.cost[j.qp]);
-            Search<LaneCfg, QuadWave<PIX>> S(W, j);
+            Search<LaneCfg, QuadWave<PIX, LPJ>> S(W, j);
             int ox, oy;
             const FullBest *f = covered ? fb + (size_t)id * fb_stride : nullptr;
             const int cost = S.run(f, fb_stride, ox, oy);
-            if ((threadIdx.x & 3) == 0)
+            if ((threadIdx.x & (LPJ - 1)) == 0)
             {
                 x265amd_me_result r;
                 r.mvx = (int16_t)ox;

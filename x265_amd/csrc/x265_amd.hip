@@ -107,7 +107,11 @@ struct x265amd_ctx
     DevBuf field_results, field_mvp;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
-    int    lane_full_area = LANE_FULL_MAX_AREA;   // largest PU of a FULL job with an exhaustive-kernel scan that the quad-per-job kernel takes
+    // Largest PU of a FULL job with an exhaustive-kernel scan that the row-per-job kernel takes (X265AMD_LANE_FULL, up to
+    // ROW_MAX_AREA).  Default: none.  Measured on MI355X the general kernel is as fast or faster on these leftovers: 1080p
+    // frames of one shape, subme 0 / 5: 16x16 0.022 / 0.077 ms against 0.026 / 0.065, 32x32 0.033 / 0.129 against 0.026 /
+    // 0.072; the tail of the 4K 10-bit frame with all 593 PUs per CTU 2.8 ms against 2.3.
+    int    lane_full_area = LANE_MAX_AREA;
     bool   hier_ok = false;               // the MV-cost tables are small enough for the hierarchical kernel's 32-bit keys
     bool   timing = false;
     int    flags = 0;
@@ -156,7 +160,7 @@ struct x265amd_joblist
     hipEvent_t ev_ran = nullptr, ev_out = nullptr;   // behind the last run / behind the last asynchronous download of the results
     bool    out_pending = false;          // a download may still read `results`: the next run waits for ev_out
     bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
-    int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., lane-per-job class ...]
+    int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., quad-per-job class ..., row-per-job class ...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
 };
@@ -376,19 +380,25 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
         hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
-    // the smallest PUs: one job per quad of lanes (full-resolution references), else the general kernel's smallest class
-    if (cnt[LANE_CLASS] > 0 && P.lane_on)
-        hipLaunchKernelGGL(k_lane<PIX>, dim3((cnt[LANE_CLASS] + 15) / 16), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[LANE_CLASS], cnt[LANE_CLASS],
-                           fb, fb_stride, d_out, c->d_evals);
-    else if (cnt[LANE_CLASS] > 0 && idx[LANE_CLASS])
+    // the smallest PUs (one job per quad of lanes) and the leftovers of exhaustive scans (one job per 16-lane row) against
+    // full-resolution references; else the general kernel, every launch taking the jobs of its own class
+    for (int gc = LANE_CLASS; gc <= ROW_CLASS; gc++)
     {
-        // (a planned list run against half-resolution references: its quad-per-job class goes through the general kernel,
-        // every launch taking the jobs of its own class)
+        const int m = cnt[gc];
+        if (m <= 0)
+            continue;
         hipStream_t st = c->lane(side_by_side ? k++ : 0);
-        const int m = cnt[LANE_CLASS];
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 1024, LR, !LR>>), dim3(m), dim3(256), 0, st, P, d_jobs, idx[LANE_CLASS], m, 2, fb, fb_stride, d_out, c->d_evals);
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[LANE_CLASS], m, 1, fb, fb_stride, d_out, c->d_evals);
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[LANE_CLASS], m, 0, fb, fb_stride, d_out, c->d_evals);
+        if (P.lane_on && gc == LANE_CLASS)
+            hipLaunchKernelGGL((k_lane<PIX, 4>), dim3((m + 15) / 16), dim3(64), 0, st, P, d_jobs, idx[gc], m, fb, fb_stride, d_out, c->d_evals);
+        else if (P.lane_on)
+            hipLaunchKernelGGL((k_lane<PIX, 16>), dim3((m + 3) / 4), dim3(64), 0, st, P, d_jobs, idx[gc], m, fb, fb_stride, d_out, c->d_evals);
+        else if (idx[gc])
+        {
+            // (a planned list run against half-resolution references)
+            hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 1024, LR, !LR>>), dim3(m), dim3(256), 0, st, P, d_jobs, idx[gc], m, 2, fb, fb_stride, d_out, c->d_evals);
+            hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[gc], m, 1, fb, fb_stride, d_out, c->d_evals);
+            hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(m), dim3(64), 0, st, P, d_jobs, idx[gc], m, 0, fb, fb_stride, d_out, c->d_evals);
+        }
     }
 }
 
@@ -398,8 +408,8 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
 {
     if (c->timing && timing_events)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr, nullptr };
-    int cnt[JOB_CLASSES] = { n, n, n, n };
+    const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    int cnt[JOB_CLASSES] = { n, n, n, n, n };
     BatchParams P = P0;
     if (idx_base)
     {
@@ -412,7 +422,7 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
         }
     }
     // with index lists every launch has work: run the classes side by side
-    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0)) : 1;
+    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0) + (cnt[4] > 0)) : 1;
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     bool lr = false;
@@ -957,14 +967,18 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         {
             std::vector<int> seg;
             for (int i = 0; i < n; i++)
-                if ((lane_job(jobs[i], full_kernel_eligible(jobs[i], bpp) || in_bundle[i], (c->flags & 128) ? 0 : c->lane_full_area) ? LANE_CLASS : job_class(jobs[i].w, jobs[i].h)) == cls)
+            {
+                const int gc = group_job_class(jobs[i], full_kernel_eligible(jobs[i], bpp) || in_bundle[i], (c->flags & 128) ? 0 : c->lane_full_area);
+                if ((gc >= 0 ? gc : job_class(jobs[i].w, jobs[i].h)) == cls)
                     seg.push_back(i);
+            }
             L->cls_count[cls] = (int)seg.size();
             if (!(c->flags & 8))        // (tuning aid: X265AMD_FLAGS bit 3 keeps the caller's job order)
             {
-                if (cls == LANE_CLASS)
+                if (cls == LANE_CLASS || cls == ROW_CLASS)
                 {
-                    // one job per quad of lanes: a wavefront takes 16 consecutive entries.  Jobs of one shape and search kind
+                    const size_t per_wave = cls == LANE_CLASS ? 16 : 4;
+                    // one job per quad / per 16-lane row of lanes: a wavefront takes 16 / 4 consecutive entries.  Jobs of one shape and search kind
                     // together (the quads of a wavefront then run the same loops), each group in picture order (their
                     // row reads share cache lines); whole wavefronts are dealt to the XCDs
                     std::stable_sort(seg.begin(), seg.end(), [&](int a, int b) {
@@ -972,15 +986,15 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
                         return std::make_tuple((int)x.ref_idx, (int)x.method, (int)x.subme, (int)x.w, (int)x.h, x.pu_y, x.pu_x) <
                                std::make_tuple((int)y.ref_idx, (int)y.method, (int)y.subme, (int)y.w, (int)y.h, y.pu_y, y.pu_x); });
                     std::vector<std::vector<int>> chunks;
-                    for (size_t a = 0; a < seg.size(); a += 16)
-                        chunks.emplace_back(seg.begin() + a, seg.begin() + std::min(seg.size(), a + 16));
+                    for (size_t a = 0; a < seg.size(); a += per_wave)
+                        chunks.emplace_back(seg.begin() + a, seg.begin() + std::min(seg.size(), a + per_wave));
                     // (only whole chunks may move: the last, partial one stays last)
-                    std::vector<std::vector<int>> whole(chunks.begin(), chunks.end() - (chunks.empty() || chunks.back().size() == 16 ? 0 : 1));
+                    std::vector<std::vector<int>> whole(chunks.begin(), chunks.end() - (chunks.empty() || chunks.back().size() == per_wave ? 0 : 1));
                     xcd_interleave(whole);
                     std::vector<int> flat;
                     for (auto &ch : whole)
                         flat.insert(flat.end(), ch.begin(), ch.end());
-                    if (!chunks.empty() && chunks.back().size() != 16)
+                    if (!chunks.empty() && chunks.back().size() != per_wave)
                         flat.insert(flat.end(), chunks.back().begin(), chunks.back().end());
                     seg.swap(flat);
                 }

@@ -1,6 +1,6 @@
 // The heavy kernel instantiations (general search, predictor-chained field, lookahead), listed once:
 // x265_amd.hip declares them `extern template` and x265_amd_part.hip defines one group of them per
-// translation unit (-DXA_PART=1..6), so the groups compile side by side (x265_amd/build.py).
+// translation unit (-DXA_PART=1..7), so the groups compile side by side (x265_amd/build.py).
 // XA_INST is `extern template` or `template`; XA_PART (optional) selects a group.
 #define XA_K_SEARCH(PIX, NW, MAXG, LR, INL)                                                                              \
     XA_INST __global__ void xa::k_search<xa::JobLds<PIX, NW, MAXG, LR, INL>>(xa::BatchParams, const x265amd_me_job*, const int*, \
@@ -21,11 +21,14 @@
     XA_INST __global__ void xa::k_lookahead<xa::JobLds<PIX, 1, 64, true, true>>(const xa::PlaneDesc*, const uint16_t*,    \
                                                                               const xa::LookPair*, int, int, int, int, int, int, int, \
                                                                               x265amd_me_result*, int*, unsigned long long*);
-#define XA_K_LANE(PIX)                                                                                                   \
-    XA_INST __global__ void xa::k_lane<PIX>(xa::BatchParams, const x265amd_me_job*, const int*, int, const xa::FullBest*, int, \
-                                            x265amd_me_result*, unsigned long long*);
+#define XA_K_LANE(PIX, LPJ)                                                                                              \
+    XA_INST __global__ void xa::k_lane<PIX, LPJ>(xa::BatchParams, const x265amd_me_job*, const int*, int, const xa::FullBest*, int, \
+                                                 x265amd_me_result*, unsigned long long*);
 #if !defined(XA_PART) || XA_PART == 6
-XA_K_LANE(uint8_t) XA_K_LANE(uint16_t)
+XA_K_LANE(uint8_t, 4) XA_K_LANE(uint16_t, 4)
+#endif
+#if !defined(XA_PART) || XA_PART == 7
+XA_K_LANE(uint8_t, 16) XA_K_LANE(uint16_t, 16)
 #endif
 #if !defined(XA_PART) || XA_PART == 1
 XA_K_SEARCH_BIG(uint8_t)
