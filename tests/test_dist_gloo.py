@@ -35,19 +35,25 @@ def _worker(rank, world, port, q):
     ref = torch.from_numpy(frames[0].copy()) if rank == 0 else torch.zeros(frames[0].shape, dtype=torch.uint8)
     xd.broadcast_plane(ref, src=0)
     assert np.array_equal(ref.numpy(), frames[0])
-    # a ring of two buffers: plane k is broadcast while plane k - 1 is in use
-    bufs = [torch.zeros(frames[0].shape, dtype=torch.uint8) for _ in range(2)]
-    ring = xd.PlaneRing(bufs, src=0, overlap=True)
-    for k in range(4):
-        if rank == 0 and ring.ready < k:
-            bufs[ring.slot(k)].copy_(torch.from_numpy(frames[k]))
-        b = ring.acquire(k)
-        assert b == k % 2 and np.array_equal(bufs[b].numpy(), frames[k]), k
-        if rank == 0:
-            bufs[ring.slot(k + 1)].copy_(torch.from_numpy(frames[k + 1]))
-        ring.prefetch(k + 1)
-        assert np.array_equal(bufs[b].numpy(), frames[k]), k       # the buffer in use is untouched
-        ring.release(k)
+    # a ring of two buffers, filled by the owner through publish(); with overlap plane k + 1 is broadcast
+    # while plane k is in use, without it (the default) the broadcast is queued by acquire(k + 1)
+    for overlap in (True, False):
+        bufs = [torch.zeros(frames[0].shape, dtype=torch.uint8) for _ in range(2)]
+        ring = xd.PlaneRing(bufs, src=0, overlap=overlap) if overlap else xd.PlaneRing(bufs, src=0)
+        assert ring.overlap == overlap
+        for k in range(4):
+            if ring.ready < k:
+                assert ring.publish(k, torch.from_numpy(frames[k])) == k % 2     # a no-op on ranks other than src
+            b = ring.acquire(k)
+            assert b == k % 2 and np.array_equal(bufs[b].numpy(), frames[k]), k
+            ring.wait_free(k + 1)                                                 # nothing to wait for on the CPU
+            ring.publish(k + 1, torch.from_numpy(frames[k + 1]))
+            ring.prefetch(k + 1)
+            assert ring.ready == (k + 1 if overlap else k)
+            assert np.array_equal(bufs[b].numpy(), frames[k]), k                  # the buffer in use is untouched
+            if rank != 0 and not overlap:
+                assert not np.array_equal(bufs[1 - b].numpy(), frames[k + 1])     # not broadcast yet
+            ring.release(k)
     # row-wise publishing: the owner hands out the padded plane 48 rows at a time
     rows = torch.from_numpy(frames[2].copy()) if rank == 0 else torch.zeros(frames[2].shape, dtype=torch.uint8)
     for r0 in range(0, rows.shape[0], 48):

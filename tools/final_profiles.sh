@@ -6,7 +6,7 @@
 #   3. HBM traffic counters (FETCH_SIZE / WRITE_SIZE, one pass each) of both legs -> gpurun_out/<tag>_pmc_traffic.json
 # Copy the files you want kept from gpurun_out/ into profiles/ (pmc_traffic.json is what bench.py reads).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench arguments...
@@ -23,11 +23,11 @@ run_stats bench --steps 20 --warmup 3 --no-cpu || exit 1
 run_stats full_leg --steps 20 --warmup 3 --only-primary || exit 1
 run_stats hex_leg --steps 20 --warmup 3 --only-primary --primary hex || exit 1
 {
-    echo "== FULL +-64 leg: exhaustive kernels (k_pack_fenc + k_full_hier), then the general kernel's launches of one step"
+    echo "== FULL +-64 leg: exhaustive kernels (k_pack_fenc + k_full_hier), then the general and group-per-job kernels' launches of one step"
     python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_full_leg.csv k_pack_fenc,k_full_hier
-    python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_full_leg.csv k_search
-    echo "== HEX + subme 5 leg: the general kernel's two launches of one step (side by side)"
-    python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_hex_leg.csv k_search
+    python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_full_leg.csv k_search,k_lane
+    echo "== HEX + subme 5 leg: the general kernel's launches and the group-per-job kernel of one step (side by side)"
+    python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_hex_leg.csv k_search,k_lane
 } > $R/gpurun_out/${TAG}_union_spans.txt 2>&1
 cat $R/gpurun_out/${TAG}_union_spans.txt
 for leg in full hex; do
@@ -71,10 +71,10 @@ for leg in ("full", "hex"):
         # one step = one k_pack_fenc + one k_full_hier launch (+ the general kernel's launches, listed above)
         out["k_full_hier_bytes_per_launch"] = total(("k_full_hier", "k_pack_fenc"), 1)
         out["k_full_hier_bytes_per_launch_fetch_doubled"] = total(("k_full_hier", "k_pack_fenc"), 2)
-        out["full_leg_k_search_bytes_per_step"] = total(("k_search",), 1)
+        out["full_leg_k_search_bytes_per_step"] = total(("k_search", "k_lane"), 1)
     else:
-        out["k_search_u8_bytes_per_launch"] = total(("k_search",), 1)
-        out["k_search_u8_bytes_per_launch_fetch_doubled"] = total(("k_search",), 2)
+        out["k_search_u8_bytes_per_launch"] = total(("k_search", "k_lane"), 1)
+        out["k_search_u8_bytes_per_launch_fetch_doubled"] = total(("k_search", "k_lane"), 2)
 json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic.json" % TAG, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("note",)}, indent=1))
 PY
