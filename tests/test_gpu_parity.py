@@ -266,6 +266,41 @@ def test_whole_cell_exhaustive_search_matches_oracle(eng, oracle, kind):
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("kind", ["motion", "flat"])
+@pytest.mark.parametrize("spread", [3, 9, 40])
+def test_whole_cell_exhaustive_search_with_a_predictor_per_pu(eng, oracle, kind, spread):
+    """The PUs of one 64x64 cell each have their OWN predictor (and with it their own window and MV-cost slice), as an
+    encoder's AMVP gives them: predictors scattered `spread` quarter-pels around a per-cell vector share the pass over
+    the cell's window (spread 3 and 9: all sub-pel phases, windows a few candidates apart, clipped differently at the
+    picture edges); spread 40 pulls some windows too far apart to share, and those PUs are scanned on their own."""
+    W, H = 200, 152
+    if kind == "flat":
+        a = np.full((H, W), 91, np.int32)
+        fr = [synth.pad_plane(a), synth.pad_plane(a)]
+    else:
+        fr = synth.make_sequence(W, H, 2, seed=626, kind=kind)
+    ids = [eng.upload_plane(f) for f in fr]
+    rng = np.random.default_rng(1000 + spread)
+    parts = []
+    for sizes, merange, qp, subme in (((64, 32, 16, 8), 24, 30, 0), ((16, 8), 64, 37, 1), ((32, 16), 9, 22, 0)):
+        for s in sizes:
+            x, y = J.square_pu_grid(W, H, s)
+            cell = (y // 64) * 8 + x // 64
+            base = rng.integers(-60, 61, size=(64, 2))[cell]
+            q = base + rng.integers(-spread, spread + 1, size=(x.size, 2))
+            parts.append(J.make_jobs(W, H, x, y, s, s, method=J.FULL, subme=subme, merange=merange, qp=qp,
+                                     qmvp=(q[:, 0].astype(np.int16), q[:, 1].astype(np.int16))))
+    jobs = np.concatenate(parts)
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8)
+    eng.eval_count(reset=True)
+    got = eng.search(ids[0], [ids[1]], jobs)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 @pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10), (16, 12)])
 @pytest.mark.parametrize("kind", ["motion", "flat"])
 def test_whole_cell_exhaustive_hadamard_search_matches_oracle(eng, oracle, bits, depth, kind):

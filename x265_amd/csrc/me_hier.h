@@ -53,6 +53,14 @@ struct HierBundle
     int32_t  qmvp_x, qmvp_y;    // the jobs' common predictor (q-pel) and QP
     int32_t  qp, ref_idx;
     int32_t  uniform;           // every job's range equals the window (no per-job masking)
+    // Jobs with DIFFERENT predictors in one bundle (me_hier.h only; pred = 0: one predictor, qmvp_x / qmvp_y above).  A job's
+    // MV cost depends on the candidate only through d = mv - (qmvp >> 2) and the phase qmvp & 3, so the kernel keeps four
+    // phase tables per axis over d = d0 .. d0 + len - 1 and every job reads them at its own offset.  Candidates whose d lies
+    // outside [ulo, uhi] (the union of the jobs' ranges, relative to their predictors) are no candidates of any job;
+    // pred = 1: every job's range is exactly [ulo, uhi] around its predictor, pred = 2: some are smaller (compared per job).
+    int32_t  pred;
+    int32_t  dx0, dy0, lx, ly;
+    int32_t  ulo_x, uhi_x, ulo_y, uhi_y;
     int32_t  metric;            // X265AMD_SAD / X265AMD_SA8D: the jobs' integer-stage metric (me_had.h; me_hier.h is SAD only)
     uint64_t cells;             // bit z: 8x8 cell z (Z-order) is covered by some job
     int32_t  job[HIER_PUS];     // job of square k (0..63: 8x8 in Z-order, 64..79: 16x16, 80..83: 32x32, 84: 64x64), -1: none
@@ -168,6 +176,37 @@ __device__ __forceinline__ uint32_t hier_mad_hi_sat(uint32_t p, uint32_t mul, ui
     return r;
 }
 
+// D = min(S0 + S1, 2^32 - 1)
+__device__ __forceinline__ uint32_t hier_add_sat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The same minimum for a job with its own predictor: cxk[x] = (x cost << 15) + column tag of candidate column x,
+// cyk[i] = (y cost << 15) + raster index of the row's first candidate; either is HIER_KEY_NONE or more for a column /
+// row outside the job's range.  The row term is the same for the 4 candidates of a row, so it is added after their
+// minimum; both steps saturate, which keeps a struck-out candidate at or above HIER_KEY_NONE.
+__device__ __forceinline__ uint32_t hier_lane_min32_pred(const unsigned long long *p, const uint32_t *cxk, const uint32_t *cyk)
+{
+    const uint32_t mul = 1u << HIER_RIDX_BITS;
+    uint32_t m = ~0u;
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+    {
+        const uint32_t lo = (uint32_t)p[i], hi = (uint32_t)(p[i] >> 32);
+        const uint32_t k0 = hier_mad_lo_sat(lo, mul, cxk[0]), k1 = hier_mad_hi_sat(lo, mul, cxk[1]);
+        const uint32_t k2 = hier_mad_lo_sat(hi, mul, cxk[2]), k3 = hier_mad_hi_sat(hi, mul, cxk[3]);
+        uint32_t r = k0 < k1 ? k0 : k1;
+        r = k2 < r ? k2 : r;
+        r = k3 < r ? k3 : r;
+        r = hier_add_sat(r, cyk[i]);
+        m = r < m ? r : m;
+    }
+    return m;
+}
+
 // The lane's minimum key of one 8x8 (SMALL8: sums <= 16320, so sum << 15 plus any mvr cannot wrap) or
 // 16x16 PU (sums <= 65280: saturating add) from packed 16-bit sums p[i] (4 candidates of row i), plus
 // optional per-job kill words
@@ -254,11 +293,58 @@ __device__ __forceinline__ void hier_job_mask(const x265amd_me_job *jobs, int ji
     }
 }
 
-template <bool MASK>
+// What hier_item_body keeps in LDS per PU of a bundle with several predictors
+struct HierPredPu
+{
+    uint32_t tx, ty;            // where candidate column 0 / row 0 of the window lies in the job's phase table (~0u: no such job)
+    uint32_t xr, yr;            // the job's own range in window coordinates: first | (last - first) << 16
+};
+
+// the job's column / row terms of the lane's 4 x HIER_R candidates (bundles with several predictors)
+template <bool KILL>
+__device__ __forceinline__ void hier_pred_terms(const uint32_t *s_tx, const uint32_t *s_ty, const HierPredPu &d, int x0, int y0,
+                                                const uint32_t *ry, uint32_t *cxk, uint32_t *cyk)
+{
+    const uint32_t *tx = s_tx + d.tx + x0, *ty = s_ty + d.ty + y0;
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+    {
+        cxk[x] = tx[x];
+        if (KILL)
+            cxk[x] = (uint32_t)(x0 + x) - (d.xr & 0xffffu) <= (d.xr >> 16) ? cxk[x] : HIER_KEY_NONE;
+    }
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+    {
+        cyk[i] = hier_add_sat(ty[i], ry[i]);
+        if (KILL)
+            cyk[i] = (uint32_t)(y0 + i) - (d.yr & 0xffffu) <= (d.yr >> 16) ? cyk[i] : HIER_KEY_NONE;
+    }
+}
+
+template <bool KILL>
+__device__ __forceinline__ unsigned long long hier_lane_min64_pred(const uint32_t (*s)[4], const uint32_t *s_tx, const uint32_t *s_ty, const HierPredPu &d,
+                                                                   int x0, int y0, int nxw, const uint32_t *ry)
+{
+    uint32_t cxk[4], cyk[HIER_R];
+    hier_pred_terms<KILL>(s_tx, s_ty, d, x0, y0, ry, cxk, cyk);
+    HierCand c;
+#pragma unroll
+    for (int i = 0; i < HIER_R; i++)
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            c.mvr[i][x] = hier_add_sat(cxk[x], cyk[i]);     // (only the cost field and "at or above HIER_KEY_NONE" are used)
+    return hier_lane_min64<false>(s, c, x0, y0, nxw, 0, 0, 0, 0);
+}
+
+// MODE 0: one predictor, every job's range is the window; 1: one predictor, per-job ranges; 2: per-job predictors, every job's
+// range is the same around its predictor; 3: per-job predictors and ranges
+template <int MODE>
 __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
                                                const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
 {
     constexpr int R = HIER_R;
+    constexpr bool MASK = MODE == 1, PRED = MODE >= 2, KILL = MODE == 3;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const PlaneDesc &ref = P.planes[P.ref_planes[B.ref_idx]];
     const int nxw = B.nxw, nyw = B.nyw, pitch = it.pitch;
@@ -267,11 +353,17 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 
     // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
     // (the window area is rounded up to an even dword count, so the 64-bit slots behind it are 8-byte aligned)
+    // several predictors: window (a multiple of 4 dwords) | HierPredPu[85] | the slots | phase tables x[4][lxp] y[4][lyp] (u32)
     uint32_t *s_win = lds;
     uint16_t *s_cx = (uint16_t*)(s_win + ((it.win_rows * pitch + 1) & ~1));
     uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
     uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
+    HierPredPu *s_pd = (HierPredPu*)(s_win + ((it.win_rows * pitch + 3) & ~3));
+    const int lxp = (B.lx + 3) & ~3, lyp = (B.ly + 3) & ~3;
+    if (PRED)
+        s_slot = (uint32_t*)(s_pd + HIER_PUS + 1);
     unsigned long long *s_big = (unsigned long long*)(s_slot + HIER_WAVES * HIER_SMALL);
+    uint32_t *s_tx = (uint32_t*)(s_big + HIER_WAVES * 5 + 1), *s_ty = s_tx + 4 * lxp;
 
     // ---- stage the window rows of this slab, the MV-cost slices, and clear the slots
     {
@@ -300,10 +392,43 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 }
         }
         const uint16_t *cost = P.cost[B.qp];
-        for (int i = tid; i < nxw; i += HIER_THREADS)
-            s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
-        for (int i = tid; i < nyw; i += HIER_THREADS)
-            s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        if (PRED)
+        {
+            // phase table entry t of an axis: the cost of d = d0 + t at phase ph, shifted into the key's cost field; the
+            // columns carry t itself as their tag (a job's columns are t = its offset + x: the same order as x)
+            for (int i = tid; i < 4 * lxp; i += HIER_THREADS)
+            {
+                const int ph = i / lxp, t = i - ph * lxp, d = B.dx0 + t;
+                s_tx[i] = (d >= B.ulo_x && d <= B.uhi_x) ? ((uint32_t)cost[(int16_t)(4 * d - ph)] << HIER_RIDX_BITS) + (uint32_t)t : HIER_KEY_NONE;
+            }
+            for (int i = tid; i < 4 * lyp; i += HIER_THREADS)
+            {
+                const int ph = i / lyp, t = i - ph * lyp, d = B.dy0 + t;
+                s_ty[i] = (d >= B.ulo_y && d <= B.uhi_y) ? (uint32_t)cost[(int16_t)(4 * d - ph)] << HIER_RIDX_BITS : HIER_KEY_NONE;
+            }
+            if (tid <= HIER_PUS)
+            {
+                HierPredPu d = { ~0u, ~0u, 0, 0 };
+                const int jid = tid < HIER_PUS ? B.job[tid] : -1;
+                if (jid >= 0)
+                {
+                    const x265amd_me_job &J = jobs[jid];
+                    // (window column 0 is mv = mvx0, i.e. d = mvx0 - (qmvp_x >> 2))
+                    d.tx = (uint32_t)((J.qmvp_x & 3) * lxp + (B.mvx0 - (J.qmvp_x >> 2) - B.dx0));
+                    d.ty = (uint32_t)((J.qmvp_y & 3) * lyp + (B.mvy0 - (J.qmvp_y >> 2) - B.dy0));
+                    d.xr = (uint32_t)(J.mvmin_x - B.mvx0) | (uint32_t)(J.mvmax_x - J.mvmin_x) << 16;
+                    d.yr = (uint32_t)(J.mvmin_y - B.mvy0) | (uint32_t)(J.mvmax_y - J.mvmin_y) << 16;
+                }
+                s_pd[tid] = d;
+            }
+        }
+        else
+        {
+            for (int i = tid; i < nxw; i += HIER_THREADS)
+                s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
+            for (int i = tid; i < nyw; i += HIER_THREADS)
+                s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        }
         for (int i = tid; i < HIER_WAVES * HIER_SMALL; i += HIER_THREADS)
             s_slot[i] = ~0u;
         if (tid < HIER_WAVES * 5)
@@ -320,18 +445,23 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
         const int yq = tk / XG, xg = tk - yq * XG;
         const int x0 = 4 * xg, y0 = R * yq;
         HierCand C;
+        uint32_t ry[R];                 // several predictors: raster index of the first candidate of the lane's rows
 #pragma unroll
         for (int i = 0; i < R; i++)
         {
             const int y = y0 + i;
             const bool vy = active && y < nyw;
-            const uint32_t cyv = s_cy[y < nyw ? y : nyw - 1];
-#pragma unroll
-            for (int x = 0; x < 4; x++)
+            ry[i] = vy ? (uint32_t)(y * nxw) : HIER_KEY_NONE;
+            if (!PRED)
             {
-                const int xx = x0 + x;
-                const uint32_t mv = (s_cx[xx < nxw ? xx : nxw - 1] + cyv) & 0xffffu;
-                C.mvr[i][x] = (vy && xx < nxw) ? (mv << HIER_RIDX_BITS) + (uint32_t)(y * nxw + xx) : HIER_KEY_NONE;
+                const uint32_t cyv = s_cy[y < nyw ? y : nyw - 1];
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const int xx = x0 + x;
+                    const uint32_t mv = (s_cx[xx < nxw ? xx : nxw - 1] + cyv) & 0xffffu;
+                    C.mvr[i][x] = (vy && xx < nxw) ? (mv << HIER_RIDX_BITS) + (uint32_t)(y * nxw + xx) : HIER_KEY_NONE;
+                }
             }
         }
         const uint32_t *wbase = s_win + (R * (yq - yq_lo)) * pitch + xg;
@@ -396,9 +526,20 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             const int j8 = B.job[z];
             if (j8 >= 0)
             {
-                uint32_t kx[4], ky[R];
-                hier_job_mask<MASK>(jobs, j8, B, x0, y0, kx, ky);
-                const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, true>(p, C, kx, ky));
+                uint32_t m;
+                if (PRED)
+                {
+                    uint32_t cxk[4], cyk[R];
+                    hier_pred_terms<KILL>(s_tx, s_ty, s_pd[z], x0, y0, ry, cxk, cyk);
+                    m = hier_lane_min32_pred(p, cxk, cyk);
+                }
+                else
+                {
+                    uint32_t kx[4], ky[R];
+                    hier_job_mask<MASK>(jobs, j8, B, x0, y0, kx, ky);
+                    m = hier_lane_min32<MASK, true>(p, C, kx, ky);
+                }
+                m = hier_wave_min_last(m);
                 if (lane == 63)
                 {
                     atomicMin(s_slot + wv * HIER_SMALL + z, m);        // (ds_min_u32: no read-back to wait for)
@@ -413,9 +554,20 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 const int j16 = B.job[64 + q];
                 if (j16 >= 0)
                 {
-                    uint32_t kx[4], ky[R];
-                    hier_job_mask<MASK>(jobs, j16, B, x0, y0, kx, ky);
-                    const uint32_t m = hier_wave_min_last(hier_lane_min32<MASK, false>(a16, C, kx, ky));
+                    uint32_t m;
+                    if (PRED)
+                    {
+                        uint32_t cxk[4], cyk[R];
+                        hier_pred_terms<KILL>(s_tx, s_ty, s_pd[64 + q], x0, y0, ry, cxk, cyk);
+                        m = hier_lane_min32_pred(a16, cxk, cyk);
+                    }
+                    else
+                    {
+                        uint32_t kx[4], ky[R];
+                        hier_job_mask<MASK>(jobs, j16, B, x0, y0, kx, ky);
+                        m = hier_lane_min32<MASK, false>(a16, C, kx, ky);
+                    }
+                    m = hier_wave_min_last(m);
                     if (lane == 63)
                     {
                         atomicMin(s_slot + wv * HIER_SMALL + 64 + q, m);
@@ -435,9 +587,15 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                     const int j32 = B.job[80 + q32];
                     if (j32 >= 0)
                     {
-                        const x265amd_me_job &J = jobs[j32];
-                        unsigned long long m = hier_lane_min64<MASK>(a32, C, x0, y0, nxw,
-                                                                     J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+                        unsigned long long m;
+                        if (PRED)
+                            m = hier_lane_min64_pred<KILL>(a32, s_tx, s_ty, s_pd[80 + q32], x0, y0, nxw, ry);
+                        else
+                        {
+                            const x265amd_me_job &J = jobs[j32];
+                            m = hier_lane_min64<MASK>(a32, C, x0, y0, nxw,
+                                                      J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+                        }
                         m = wave_min_u64(m);
                         if (lane == 0)
                             atomicMin(s_big + wv * 5 + q32, m);         // (ds_min_u64)
@@ -460,9 +618,15 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
         const int j64 = B.job[84];
         if (j64 >= 0)
         {
-            const x265amd_me_job &J = jobs[j64];
-            unsigned long long m = hier_lane_min64<MASK>(a64, C, x0, y0, nxw,
-                                                         J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+            unsigned long long m;
+            if (PRED)
+                m = hier_lane_min64_pred<KILL>(a64, s_tx, s_ty, s_pd[84], x0, y0, nxw, ry);
+            else
+            {
+                const x265amd_me_job &J = jobs[j64];
+                m = hier_lane_min64<MASK>(a64, C, x0, y0, nxw,
+                                          J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
+            }
             m = wave_min_u64(m);
             if (lane == 0)
                 atomicMin(s_big + wv * 5 + 4, m);
@@ -490,6 +654,8 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 {
                     cost = (int)(m >> HIER_RIDX_BITS);
                     ridx = (int)(m & ((1u << HIER_RIDX_BITS) - 1));
+                    if (PRED)       // (the key's low bits hold row start + column tag = raster index + the job's table offset)
+                        ridx -= (int)(s_pd[tid].tx % (uint32_t)lxp);
                 }
             }
             else
@@ -525,10 +691,14 @@ __global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const
     const HierItem &it = items[id];
     const HierBundle &B = bundles[it.bundle];
     const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HIER_FENC_DW);
-    if (B.uniform)
-        hier_item_body<false>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    if (B.pred == 1)
+        hier_item_body<2>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    else if (B.pred)
+        hier_item_body<3>(P, jobs, B, it, pf, fb, fb_stride, lds);
+    else if (B.uniform)
+        hier_item_body<0>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else
-        hier_item_body<true>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        hier_item_body<1>(P, jobs, B, it, pf, fb, fb_stride, lds);
 }
 
 } // namespace xa

@@ -599,6 +599,7 @@ void plan_group(const x265amd_me_job *jobs, int bpp, std::vector<int> members, s
 // out the lighter work at the picture's top and bottom edges, where search ranges are clipped).
 constexpr int N_XCD = 8, XCD_BANDS = 2;
 bool g_no_xcd_bands = false;       // tuning aid: X265AMD_FLAGS bit 2 keeps picture order
+bool g_hier_one_pred = false;      // tuning aid: X265AMD_FLAGS bit 8 keeps jobs with different predictors in separate bundles
 template <class T>
 void xcd_interleave(std::vector<T> &v)
 {
@@ -727,22 +728,87 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         int kind_unused;
         if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy, kind_unused) >= 0) && !(had && quads_out && quad_slot(j, gx, gy) >= 0))
             continue;
-        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), (int)j.qmvp_x, (int)j.qmvp_y, gy, gx)].push_back(i);
+        // (the hierarchical kernel takes jobs with different predictors in one bundle: they are clustered by window below)
+        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), gy, gx, (had || g_hier_one_pred) ? (int)j.qmvp_x : 0,
+                               (had || g_hier_one_pred) ? (int)j.qmvp_y : 0)].push_back(i);
     }
     for (auto &g : groups)
     {
+      // Clusters of the cell's jobs: jobs with one predictor stay together; groups with different predictors join while the
+      // union of their windows stays within an eighth (at least 4 candidates) of the larger one per axis, so that the
+      // shared pass does not scan much more than each job's own range.
+      std::vector<std::vector<int>> clusters;
+      if (had || g_hier_one_pred)
+          clusters.push_back(g.second);
+      else
+      {
+          struct Sub { std::vector<int> jobs; int x0, y0, x1, y1; long area; };
+          std::map<std::pair<int, int>, Sub> subs;
+          for (int i : g.second)
+          {
+              const x265amd_me_job &j = jobs[i];
+              auto itb = subs.find({ j.qmvp_x, j.qmvp_y });
+              if (itb == subs.end())
+                  itb = subs.insert({ { j.qmvp_x, j.qmvp_y }, Sub{ {}, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, 0 } }).first;
+              Sub &sb = itb->second;
+              sb.jobs.push_back(i);
+              sb.x0 = std::min(sb.x0, (int)j.mvmin_x); sb.y0 = std::min(sb.y0, (int)j.mvmin_y);
+              sb.x1 = std::max(sb.x1, (int)j.mvmax_x); sb.y1 = std::max(sb.y1, (int)j.mvmax_y);
+              sb.area += (long)j.w * j.h;
+          }
+          std::vector<Sub*> order;
+          for (auto &kv : subs)
+              order.push_back(&kv.second);
+          std::stable_sort(order.begin(), order.end(), [](const Sub *a, const Sub *b) { return a->area > b->area; });
+          std::vector<Sub> cl;
+          for (Sub *sb : order)
+          {
+              int best = -1;
+              long best_grow = 0;
+              for (size_t k = 0; k < cl.size(); k++)
+              {
+                  const Sub &c2 = cl[k];
+                  const int ux0 = std::min(c2.x0, sb->x0), uy0 = std::min(c2.y0, sb->y0), ux1 = std::max(c2.x1, sb->x1), uy1 = std::max(c2.y1, sb->y1);
+                  const int nxa = std::max(c2.x1 - c2.x0, sb->x1 - sb->x0) + 1, nya = std::max(c2.y1 - c2.y0, sb->y1 - sb->y0) + 1;
+                  if (ux1 - ux0 + 1 > nxa + std::max(4, nxa / 8) || uy1 - uy0 + 1 > nya + std::max(4, nya / 8))
+                      continue;
+                  const long grow = (long)(ux1 - ux0 + 1) * (uy1 - uy0 + 1) - (long)(c2.x1 - c2.x0 + 1) * (c2.y1 - c2.y0 + 1);
+                  if (best < 0 || grow < best_grow)
+                  {
+                      best = (int)k;
+                      best_grow = grow;
+                  }
+              }
+              if (best < 0)
+                  cl.push_back(*sb);
+              else
+              {
+                  Sub &c2 = cl[best];
+                  c2.jobs.insert(c2.jobs.end(), sb->jobs.begin(), sb->jobs.end());
+                  c2.x0 = std::min(c2.x0, sb->x0); c2.y0 = std::min(c2.y0, sb->y0);
+                  c2.x1 = std::max(c2.x1, sb->x1); c2.y1 = std::max(c2.y1, sb->y1);
+              }
+          }
+          for (Sub &c2 : cl)
+          {
+              std::sort(c2.jobs.begin(), c2.jobs.end());
+              clusters.push_back(c2.jobs);
+          }
+      }
+      for (const std::vector<int> &members : clusters)
+      {
         HierBundle B;
         memset(&B, 0, sizeof(B));
         for (int k = 0; k < HIER_PUS; k++)
             B.job[k] = -1;
-        const int gy = std::get<4>(g.first), gx = std::get<5>(g.first);
+        const int gy = std::get<2>(g.first), gx = std::get<3>(g.first);
         int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
         double old_work = 0;
         std::vector<int> taken;
         std::vector<HierBundle::Rect> rects[21];
         HierQuads QJ;
         memset(&QJ, 0xff, sizeof(QJ));       // every job -1
-        for (int i : g.second)
+        for (int i : members)
         {
             const x265amd_me_job &j = jobs[i];
             const int cx = (j.pu_x - gx * 64) >> 3, cy = (j.pu_y - gy * 64) >> 3, z = zidx(cx, cy);
@@ -806,7 +872,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if ((int64_t)nxw * nyw > (1 << HIER_RIDX_BITS))
             continue;
         const double hier_work = (double)__builtin_popcountll(B.cells) * 64.0 * nxw * nyw;
-        const bool had_sad = had && jobs[g.second[0]].icost == X265AMD_SAD;
+        const bool had_sad = had && jobs[members[0]].icost == X265AMD_SAD;
         if (!had ? hier_work * 1.25 > old_work : had_sad && hier_work > old_work)
             continue;
         B.uniform = 1;
@@ -818,6 +884,37 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
         B.metric = j0.icost;
+        // several predictors: the phase tables' extent (me_hier.h)
+        int lxp = 0, lyp = 0;
+        for (int i : taken)
+            if (jobs[i].qmvp_x != j0.qmvp_x || jobs[i].qmvp_y != j0.qmvp_y)
+                B.pred = 1;
+        if (B.pred)
+        {
+            int qx0 = INT32_MAX, qx1 = INT32_MIN, qy0 = INT32_MAX, qy1 = INT32_MIN;
+            B.ulo_x = B.ulo_y = INT32_MAX; B.uhi_x = B.uhi_y = INT32_MIN;
+            for (int i : taken)
+            {
+                const x265amd_me_job &j = jobs[i];
+                const int qx = j.qmvp_x >> 2, qy = j.qmvp_y >> 2;
+                qx0 = std::min(qx0, qx); qx1 = std::max(qx1, qx); qy0 = std::min(qy0, qy); qy1 = std::max(qy1, qy);
+                B.ulo_x = std::min(B.ulo_x, j.mvmin_x - qx); B.uhi_x = std::max(B.uhi_x, j.mvmax_x - qx);
+                B.ulo_y = std::min(B.ulo_y, j.mvmin_y - qy); B.uhi_y = std::max(B.uhi_y, j.mvmax_y - qy);
+            }
+            for (int i : taken)
+            {
+                const x265amd_me_job &j = jobs[i];
+                const int qx = j.qmvp_x >> 2, qy = j.qmvp_y >> 2;
+                if (j.mvmin_x - qx != B.ulo_x || j.mvmax_x - qx != B.uhi_x || j.mvmin_y - qy != B.ulo_y || j.mvmax_y - qy != B.uhi_y)
+                    B.pred = 2;
+            }
+            B.dx0 = x0 - qx1; B.dy0 = y0 - qy1;
+            B.lx = nxw + 4 + qx1 - qx0; B.ly = nyw + 4 + qy1 - qy0;
+            lxp = (B.lx + 3) & ~3; lyp = (B.ly + 3) & ~3;
+            // (a 32-bit key's low bits hold raster index + column offset of the job)
+            if ((int64_t)nxw * nyw + B.lx > (1 << HIER_RIDX_BITS))
+                continue;
+        }
         int n_rect = 0;
         for (int gk = 0; gk < 21; gk++)
         {
@@ -852,7 +949,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if (had && per * NC > (1 << HAD_RIDX_BITS))
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
-        const int fixed = 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) + 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
+        const int fixed = (B.pred ? 16 * (lxp + lyp) + 16 * (HIER_PUS + 1) + 32 : 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3))) +
+                          4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
                           (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0) + (B.quads ? 4 * (threads / 64) * HIER_QUAD_PUS : 0);
         bool fits = true;
         std::vector<HierItem> mine;
@@ -884,6 +982,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
             *had_threads_out |= 1 << 16;        // (bit 16: some bundle has rectangular PUs)
         if (B.quads && had_threads_out)
             *had_threads_out |= 1 << 17;        // (bit 17: some bundle has PUs with 4- or 12-pixel sides)
+      }
     }
     if (bundles.empty())
         lds_bytes = 0;
@@ -958,6 +1057,17 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         if (int rc = ensure(c, L->hier_fenc, hbundles.size() * (size_t)HIER_FENC_DW * 4)) return rc;
         HIPCHK(c, hipMemcpyAsync(L->hier_bundles.p, hbundles.data(), hbundles.size() * sizeof(HierBundle), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L->hier_items.p, hitems.data(), hitems.size() * sizeof(HierItem), hipMemcpyHostToDevice, c->stream));
+    }
+    if (getenv("X265AMD_PLAN_DEBUG"))       // tuning aid: what the planner made of the list
+    {
+        int modes[4] = { 0, 0, 0, 0 }, nb = 0;
+        for (const HierBundle &B : hbundles)
+            modes[B.pred ? 1 + B.pred : B.uniform ? 0 : 1]++;
+        for (int i = 0; i < n; i++)
+            nb += in_bundle[i];
+        fprintf(stderr, "x265amd plan: %d jobs, %d in bundles; shared-window SAD pass: %zu bundles (%d one window, %d per-job ranges, %d per-job "
+                "predictors, %d both) in %zu items, LDS %d; candidate-per-lane pass: %zu bundles in %zu items\n", n, nb, hbundles.size(),
+                modes[0], modes[1], modes[2], modes[3], hitems.size(), L->hier_lds_bytes, dbundles.size(), ditems.size());
     }
     // job classes and launch order (after the bundles are known: a FULL job whose scan an exhaustive kernel runs leaves
     // only a handful of evaluations to the search kernels)
@@ -1353,6 +1463,7 @@ int x265amd_create(int device, x265amd_ctx **out)
     {
         c->flags = atoi(ev);
         g_no_xcd_bands = (c->flags & 4) != 0;
+        g_hier_one_pred = (c->flags & 256) != 0;
     }
     if (const char *ev = getenv("X265AMD_LANE_FULL"))    // tuning aid: see lane_full_area (at least LANE_MAX_AREA)
         c->lane_full_area = std::max(LANE_MAX_AREA, std::min(4096, atoi(ev)));
