@@ -383,6 +383,35 @@ def test_every_partition_of_the_ctus_through_the_shared_pass(eng, oracle, bits, 
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10)])
+@pytest.mark.parametrize("icost", [J.SA8D, J.SAD])
+def test_every_partition_with_a_predictor_per_pu(eng, oracle, bits, depth, icost):
+    """The 593 PUs of every CTU, each with its own predictor a few quarter-pels around a per-CTU vector (so its own
+    window and MV-cost slice), still share the pass over the CTU's window."""
+    W, H = 152, 136
+    fr = synth.make_sequence(W, H, 2, seed=321, bit_depth=depth)
+    ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
+    jobs = np.concatenate([J.all_partition_jobs(W, H, method=J.FULL, subme=0, merange=9, qp=27, icost=icost),
+                           J.all_partition_jobs(W, H, cu_sizes=(16, 8), method=J.FULL, subme=1, merange=5, qp=33, icost=icost)])
+    rng = np.random.default_rng(77)
+    ctu = (jobs["pu_y"] // 64) * 4 + jobs["pu_x"] // 64
+    q = rng.integers(-30, 31, size=(16, 2))[ctu] + rng.integers(-6, 7, size=(jobs.size, 2))
+    for k, (mr, sel) in enumerate(((9, jobs["subme"] == 0), (5, jobs["subme"] == 1))):
+        jobs["qmvp_x"][sel], jobs["qmvp_y"][sel] = q[sel, 0], q[sel, 1]
+        r = J.search_range(W, H, jobs["pu_x"][sel], jobs["pu_y"][sel], q[sel, 0], q[sel, 1], mr)
+        jobs["mvmin_x"][sel], jobs["mvmin_y"][sel], jobs["mvmax_x"][sel], jobs["mvmax_y"][sel] = r
+    exp, evals = oracle.search(fr[0], [fr[1]], jobs, threads=8, bit_depth=depth)
+    eng.eval_count(reset=True)
+    jl = eng.make_joblist(jobs, bytes_per_px=bits // 8)
+    got = jl.run(ids[0], [ids[1]])
+    jl.close()
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (len(bad), bad[:5], jobs[bad[:3]], got[bad[:3]], exp[bad[:3]])
+    assert eng.eval_count() == evals
+    for i in ids:
+        eng.release_plane(i)
+
+
 @pytest.mark.parametrize("depth", [12, 14])
 def test_shared_pass_limits_fall_back_to_the_other_kernels(eng, oracle, depth):
     """What the candidate-per-lane exhaustive kernel does not take must come out right through the other kernels:

@@ -395,9 +395,11 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
     // (the window area is rounded up to an even dword count, so the 64-bit slots behind it are 8-byte aligned)
     uint32_t *s_win = lds;
+    // (bundles with per-job ranges or predictors: cx[4][lxp] cy[4][lyp])
+    const int lxp = (B.lx + 3) & ~3, lyp = (B.ly + 3) & ~3;
     uint16_t *s_cx = (uint16_t*)(s_win + ((it.win_rows * pitch + 1) & ~1));
-    uint16_t *s_cy = s_cx + ((nxw + 3) & ~3);
-    uint32_t *s_slot = (uint32_t*)(s_cy + ((nyw + 3) & ~3));
+    uint16_t *s_cy = s_cx + (MASK ? 4 * lxp : (nxw + 3) & ~3);
+    uint32_t *s_slot = (uint32_t*)(s_cy + (MASK ? 4 * lyp : (nyw + 3) & ~3));
     unsigned long long *s_big = (unsigned long long*)(s_slot + HAD_WAVES * HIER_SMALL);
     // bundles with rectangular PUs: 64-bit slots [waves][HIER_MAX_RECT]; with PUs of 4- or 12-pixel sides: 32-bit
     // slots [waves][HIER_QUAD_PUS] behind them (cell z, half k at 4 z + k; block q, partition k at 256 + 8 q + k)
@@ -424,10 +426,27 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
                 s_win[r * pitch + c] = ld_u32(r0 + a * PB);
             }
         const uint16_t *cost = P.cost[B.qp];
-        for (int i = tid; i < nxw; i += nthreads)
-            s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
-        for (int i = tid; i < nyw; i += nthreads)
-            s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        if (MASK)
+        {
+            // per-job ranges and predictors: four phase tables per axis over d = mv - (qmvp >> 2) (HierBundle::pred)
+            for (int i = tid; i < 4 * lxp; i += nthreads)
+            {
+                const int ph = i / lxp;
+                s_cx[i] = cost[(int16_t)(4 * (B.dx0 + i - ph * lxp) - ph)];
+            }
+            for (int i = tid; i < 4 * lyp; i += nthreads)
+            {
+                const int ph = i / lyp;
+                s_cy[i] = cost[(int16_t)(4 * (B.dy0 + i - ph * lyp) - ph)];
+            }
+        }
+        else
+        {
+            for (int i = tid; i < nxw; i += nthreads)
+                s_cx[i] = cost[(int16_t)((int16_t)((B.mvx0 + i) << 2) - B.qmvp_x)];
+            for (int i = tid; i < nyw; i += nthreads)
+                s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
+        }
         for (int i = tid; i < HAD_WAVES * HIER_SMALL; i += nthreads)
             s_slot[i] = ~0u;
         if (tid < HAD_WAVES * 5)
@@ -448,8 +467,17 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         for (int c = 0; c < NC; c++)
         {
             valid[c] = active && x + c < nxw;
-            mv[c] = (s_cx[x + c < nxw ? x + c : nxw - 1] + s_cy[y]) & 0xffffu;
+            if (!MASK)
+                mv[c] = (s_cx[x + c < nxw ? x + c : nxw - 1] + s_cy[y]) & 0xffffu;
         }
+        // the MV costs of the lane's candidates for job J (its own predictor)
+        auto job_mv = [&](const x265amd_me_job &J, uint32_t *m) {
+            const uint16_t *tx = s_cx + (J.qmvp_x & 3) * lxp + (B.mvx0 - (J.qmvp_x >> 2) - B.dx0) + x;
+            const uint32_t cyv = s_cy[(J.qmvp_y & 3) * lyp + (B.mvy0 - (J.qmvp_y >> 2) - B.dy0) + y];
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                m[c] = (tx[c] + cyv) & 0xffffu;
+        };
         const uint32_t lidx = (uint32_t)((y - y_lo) * nxw + x - x_lo);  // slab-local index of candidate 0
         const uint32_t ridx = (uint32_t)(y * nxw + x);                  // its raster index in the window
         const uint32_t *wbase = s_win + (y - y_lo) * pitch;
@@ -476,20 +504,26 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         };
         auto key32 = [&](int jid, const uint32_t *v) -> uint32_t {
             uint32_t k = ~0u;
+            uint32_t mj[NC];
+            if (MASK)
+                job_mv(jobs[jid], mj);
 #pragma unroll
             for (int c = 0; c < NC; c++)
             {
-                const uint32_t kc = kill(jid, c) ? ~0u : ((v[c] + mv[c]) << HAD_RIDX_BITS) | (lidx + c);
+                const uint32_t kc = kill(jid, c) ? ~0u : ((v[c] + (MASK ? mj[c] : mv[c])) << HAD_RIDX_BITS) | (lidx + c);
                 k = kc < k ? kc : k;
             }
             return k;
         };
         auto key64 = [&](int jid, const uint32_t *v) -> unsigned long long {
             unsigned long long k = ~0ull;
+            uint32_t mj[NC];
+            if (MASK)
+                job_mv(jobs[jid], mj);
 #pragma unroll
             for (int c = 0; c < NC; c++)
             {
-                const unsigned long long kc = kill(jid, c) ? ~0ull : ((unsigned long long)(v[c] + mv[c]) << 32) | (ridx + c);
+                const unsigned long long kc = kill(jid, c) ? ~0ull : ((unsigned long long)(v[c] + (MASK ? mj[c] : mv[c])) << 32) | (ridx + c);
                 k = kc < k ? kc : k;
             }
             return k;
@@ -866,8 +900,9 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
     }
 }
 
+// (16-bit pixels: 4 wavefronts per SIMD hide the LDS latency of the row reads; the register allocator is held to that)
 template <typename PIX, bool RECTS, bool QUADS>
-__global__ void __launch_bounds__(HAD_THREADS_BIG) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+__global__ void __launch_bounds__(HAD_THREADS_BIG) __attribute__((amdgpu_waves_per_eu(sizeof(PIX) == 2 ? 4 : 1))) k_full_had(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                               const HierItem *items, int n_items, const uint32_t *packed,
                                                               const HierQuads *quads, FullBest *fb, int fb_stride)
 {

@@ -728,9 +728,9 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         int kind_unused;
         if (!is_square(j, gx, gy) && !(had && rect_kind(j, gx, gy, kind_unused) >= 0) && !(had && quads_out && quad_slot(j, gx, gy) >= 0))
             continue;
-        // (the hierarchical kernel takes jobs with different predictors in one bundle: they are clustered by window below)
-        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), gy, gx, (had || g_hier_one_pred) ? (int)j.qmvp_x : 0,
-                               (had || g_hier_one_pred) ? (int)j.qmvp_y : 0)].push_back(i);
+        // (jobs with different predictors share a bundle: they are clustered by window below)
+        groups[std::make_tuple((int)j.ref_idx, (int)j.qp | (j.method << 8) | (j.icost << 16), gy, gx, g_hier_one_pred ? (int)j.qmvp_x : 0,
+                               g_hier_one_pred ? (int)j.qmvp_y : 0)].push_back(i);
     }
     for (auto &g : groups)
     {
@@ -738,7 +738,7 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
       // union of their windows stays within an eighth (at least 4 candidates) of the larger one per axis, so that the
       // shared pass does not scan much more than each job's own range.
       std::vector<std::vector<int>> clusters;
-      if (had || g_hier_one_pred)
+      if (g_hier_one_pred)
           clusters.push_back(g.second);
       else
       {
@@ -884,12 +884,11 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         B.mvx0 = x0; B.mvy0 = y0; B.nxw = nxw; B.nyw = nyw;
         B.qmvp_x = j0.qmvp_x; B.qmvp_y = j0.qmvp_y; B.qp = j0.qp; B.ref_idx = j0.ref_idx;
         B.metric = j0.icost;
-        // several predictors: the phase tables' extent (me_hier.h)
+        // per-job predictors / ranges: the phase tables' extent (HierBundle::pred)
         int lxp = 0, lyp = 0;
         for (int i : taken)
             if (jobs[i].qmvp_x != j0.qmvp_x || jobs[i].qmvp_y != j0.qmvp_y)
                 B.pred = 1;
-        if (B.pred)
         {
             int qx0 = INT32_MAX, qx1 = INT32_MIN, qy0 = INT32_MAX, qy1 = INT32_MIN;
             B.ulo_x = B.ulo_y = INT32_MAX; B.uhi_x = B.uhi_y = INT32_MIN;
@@ -901,19 +900,22 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                 B.ulo_x = std::min(B.ulo_x, j.mvmin_x - qx); B.uhi_x = std::max(B.uhi_x, j.mvmax_x - qx);
                 B.ulo_y = std::min(B.ulo_y, j.mvmin_y - qy); B.uhi_y = std::max(B.uhi_y, j.mvmax_y - qy);
             }
-            for (int i : taken)
-            {
-                const x265amd_me_job &j = jobs[i];
-                const int qx = j.qmvp_x >> 2, qy = j.qmvp_y >> 2;
-                if (j.mvmin_x - qx != B.ulo_x || j.mvmax_x - qx != B.uhi_x || j.mvmin_y - qy != B.ulo_y || j.mvmax_y - qy != B.uhi_y)
-                    B.pred = 2;
-            }
+            if (B.pred)
+                for (int i : taken)
+                {
+                    const x265amd_me_job &j = jobs[i];
+                    const int qx = j.qmvp_x >> 2, qy = j.qmvp_y >> 2;
+                    if (j.mvmin_x - qx != B.ulo_x || j.mvmax_x - qx != B.uhi_x || j.mvmin_y - qy != B.ulo_y || j.mvmax_y - qy != B.uhi_y)
+                        B.pred = 2;
+                }
             B.dx0 = x0 - qx1; B.dy0 = y0 - qy1;
             B.lx = nxw + 4 + qx1 - qx0; B.ly = nyw + 4 + qy1 - qy0;
             lxp = (B.lx + 3) & ~3; lyp = (B.ly + 3) & ~3;
-            // (a 32-bit key's low bits hold raster index + column offset of the job)
-            if ((int64_t)nxw * nyw + B.lx > (1 << HIER_RIDX_BITS))
+            // (the hierarchical kernel's 32-bit keys hold raster index + column offset of the job in their low bits)
+            if (!had && B.pred && (int64_t)nxw * nyw + B.lx > (1 << HIER_RIDX_BITS))
                 continue;
+            if (had && B.pred)      // (the candidate-per-lane kernel has one form for per-job ranges and predictors)
+                B.uniform = 0;
         }
         int n_rect = 0;
         for (int gk = 0; gk < 21; gk++)
@@ -949,7 +951,8 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
         if (had && per * NC > (1 << HAD_RIDX_BITS))
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
-        const int fixed = (B.pred ? 16 * (lxp + lyp) + 16 * (HIER_PUS + 1) + 32 : 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3))) +
+        const int fixed = (had ? (B.uniform ? 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) : 8 * (lxp + lyp))
+                               : B.pred ? 16 * (lxp + lyp) + 16 * (HIER_PUS + 1) + 32 : 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3))) +
                           4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
                           (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0) + (B.quads ? 4 * (threads / 64) * HIER_QUAD_PUS : 0);
         bool fits = true;
