@@ -355,6 +355,22 @@ int x265amd_field_me(x265amd_ctx *ctx, int enc_plane, int ref_plane, int pu_w, i
  * [f * (width / pu_w) * (height / pu_h) ...). */
 int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, int pu_w, int pu_h,
                            int merange, int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
+/* The same with a PU size and a partition mode PER FIELD, e.g. one field per quadtree depth of a frame, or the 2NxN and
+ * Nx2N fields beside the 2Nx2N one (the PartSize loop around predInterSearch in TEncCu::xCompressCU, Lib/TLibEncoder/TEncCu.cpp).
+ * Consecutive fields of one size and mode share a launch; the launches run side by side on different streams, so the call takes
+ * about as long as its longest chain (the smallest PUs).
+ *   part_mode[f] (NULL: all 0) = 0: 2Nx2N - every PU is its own CU;
+ *                                1: 2NxN - CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 are their upper / lower parts;
+ *                                2: Nx2N - CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts.
+ * CUs are taken in raster order, the two parts of a CU one after the other (the partIdx loop, TEncSearch.cpp:2341).  Against
+ * mode 0: clipMv and xSetSearchRange work from the CU's position; the upper part of a 2NxN CU takes candidate A from its
+ * below-left neighbour (the lower part of the CU to its left, which the left scan of TComDataCU::fillMvpCand asks first,
+ * Lib/TLibCommon/TComDataCU.cpp:2574-2588); its lower part has the upper part above it and nothing coded above-right.
+ * Only whole CUs are searched: a 2NxN grid has 2 * (height / (2 pu_h)) PU rows, an Nx2N grid 2 * (width / (2 pu_w)) columns.
+ * out / out_mvp hold the fields one after the other, field f as gw_f x gh_f entries in raster order of its PU grid. */
+int x265amd_field_me_multi(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w,
+                           const int *pu_h, const int *part_mode, int merange, int method, int subme, int qp,
+                           x265amd_me_result *out, int16_t *out_mvp);
 const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last

@@ -36,16 +36,17 @@ class RefChain:
     def __init__(self, ref):
         self.ref = ref
 
-    def field_run(self, enc, refp, pw, ph, mr, method, subme, qp):
-        return self.ref.field_me(enc, refp, pw, ph, mr, method, subme, qp)
+    def field_run(self, enc, refp, pw, ph, mr, method, subme, qp, part_mode=0):
+        return self.ref.field_me(enc, refp, pw, ph, mr, method, subme, qp, part_mode=part_mode)
 
 
 def gen_chain():
-    """whole-frame fields with predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me)"""
+    """whole-frame fields with predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me_parts)"""
     for bits in (8, 16):
         ref = Reference(bits)
         ref.set_bit_depth(8 if bits == 8 else 10)
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_u%d.npz" % bits), **G.run_chain_suite(RefChain(ref), bits))
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_parts_u%d.npz" % bits), **G.run_chain_parts_suite(RefChain(ref), bits))
         print("chain fields, bits", bits)
 
 

@@ -154,12 +154,18 @@ int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, in
                                   : lookahead_me_u16(enc, ref, cuw, cuh, merange, method, subme, qp, out);
 }
 
+int64_t meo_field_me_parts(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
+                           int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
+{
+    cost_table_for_qp(qp);
+    return enc->bytes_per_px == 1 ? field_me_u8(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, merange, method, subme, qp, out, out_mvp)
+                                  : field_me_u16(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, merange, method, subme, qp, out, out_mvp);
+}
+
 int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int merange,
                      int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
 {
-    cost_table_for_qp(qp);
-    return enc->bytes_per_px == 1 ? field_me_u8(enc, ref, pic_w, pic_h, pu_w, pu_h, merange, method, subme, qp, out, out_mvp)
-                                  : field_me_u16(enc, ref, pic_w, pic_h, pu_w, pu_h, merange, method, subme, qp, out, out_mvp);
+    return meo_field_me_parts(enc, ref, pic_w, pic_h, pu_w, pu_h, 0, merange, method, subme, qp, out, out_mvp);
 }
 
 int64_t meo_search_batch(const meo_plane *enc, const meo_plane *refs, const meo_job *jobs, int n,

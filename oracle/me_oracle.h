@@ -115,6 +115,10 @@ int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, in
  * out[gx + gy * (pic_w / pu_w)], out_mvp (optional) = the predictor used, (x, y) pairs; returns the evaluations */
 int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int merange,
                      int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
+/* the same for the parts of 2NxN (part_mode 1: CUs of pu_w x 2 pu_h) or Nx2N CUs (2: CUs of 2 pu_w x pu_h), 0 = as above:
+ * CUs in raster order, their two parts one after the other; whole CUs only (an odd last PU row / column is left out) */
+int64_t meo_field_me_parts(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
+                           int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
 
 /* run n jobs (one enc plane, jobs[i].ref_idx selects refs[]) with `threads` OpenMP threads
  * (one search state per thread); returns total number of block-cost evaluations. */

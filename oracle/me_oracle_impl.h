@@ -1114,23 +1114,38 @@ static inline int SUF(clipi)(int v, int lo, int hi)
 }
 
 /* The searches of TEncSearch::predInterSearch (Lib/TLibEncoder/TEncSearch.cpp:2341-2455) for a uniform grid of
- * pu_w x pu_h PUs in raster order: AMVP candidates A = left MV, B = first of above-right / above / above-left MV
+ * pu_w x pu_h PUs, CUs in raster order: AMVP candidates A = left MV, B = first of above-right / above / above-left MV
  * (dropped if equal to A), zero-padded to two; mvp = the one with the smaller template SAD at the clipMv'ed
  * candidate (xEstimateMvPredAMVP :2767-2819, xGetTemplateCost :2944-2958, TComDataCU::clipMv
  * TComDataCU.cpp:2724-2736; equal index bits, ties keep the first); range = xSetSearchRange (:3007-3024);
- * motionEstimate with the three neighbour MVs m_mvPredictors (:2366-2368) as candidates. */
-static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h,
+ * motionEstimate with the three neighbour MVs m_mvPredictors (:2366-2368) as candidates.
+ * part_mode 0: every PU is the 2Nx2N PU of its own CU.  1 (2NxN): CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 their upper /
+ * lower parts; 2 (Nx2N): CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts; the parts of a CU are
+ * searched one after the other (the partIdx loop, :2341).  clipMv / xSetSearchRange take the CU's position.  Where the
+ * neighbour positions of TComDataCU::fillMvpCand (TComDataCU.cpp:2553-2633) fall: the upper part of a 2NxN CU has the
+ * lower part of the CU to its left below-left of it, coded already, and the left scan asks below-left first (:2574-2588),
+ * so A is that PU's MV; the lower part has the upper part of its own CU above it and nothing coded above-right. */
+static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
                              int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
 {
     SUF(state) *st = (SUF(state)*)malloc(sizeof(SUF(state)));
     int64_t evals = 0;
-    const int gw = pic_w / pu_w, gh = pic_h / pu_h, max_cu = 64;
-    for (int gy = 0; gy < gh; gy++)
+    const int max_cu = 64;
+    int gw = pic_w / pu_w, gh = pic_h / pu_h;
+    if (part_mode == 1) gh &= ~1;
+    if (part_mode == 2) gw &= ~1;
+    const int parts = part_mode == 1 ? 2 : 1;
+    for (int row = 0; row < gh / parts; row++)
     {
         for (int gx = 0; gx < gw; gx++)
-        {
+          for (int part = 0; part < parts; part++)
+          {
+            const int gy = row * parts + part, lower = part == 1;
             const int xy = gx + gy * gw, px = gx * pu_w, py = gy * pu_h;
-            const int have_l = gx > 0, have_a = gy > 0, have_ar = gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
+            const int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
+            const int have_l = gx > 0, have_a = gy > 0, have_ar = !lower && gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
+            /* candidate A: the left neighbour; for the upper part of a 2NxN CU the below-left one */
+            const int xa = part_mode == 1 && !lower ? xy + gw - 1 : xy - 1;
             int c[2][2] = { { 0, 0 }, { 0, 0 } };
             int bx = 0, by = 0, have_b = 0;
             if (have_ar)      { bx = out[xy - gw + 1].mvx; by = out[xy - gw + 1].mvy; have_b = 1; }
@@ -1138,7 +1153,7 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             else if (have_al) { bx = out[xy - gw - 1].mvx; by = out[xy - gw - 1].mvy; have_b = 1; }
             if (have_l)
             {
-                c[0][0] = out[xy - 1].mvx; c[0][1] = out[xy - 1].mvy;
+                c[0][0] = out[xa].mvx; c[0][1] = out[xa].mvy;
                 if (have_b && !(bx == c[0][0] && by == c[0][1]))
                 {
                     c[1][0] = bx; c[1][1] = by;
@@ -1148,8 +1163,8 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             {
                 c[0][0] = bx; c[0][1] = by;
             }
-            const int xmax = (pic_w + 8 - px - 1) << 2, xmin = (-max_cu - 8 - px + 1) << 2;
-            const int ymax = (pic_h + 8 - py - 1) << 2, ymin = (-max_cu - 8 - py + 1) << 2;
+            const int xmax = (pic_w + 8 - cux - 1) << 2, xmin = (-max_cu - 8 - cux + 1) << 2;
+            const int ymax = (pic_h + 8 - cuy - 1) << 2, ymin = (-max_cu - 8 - cuy + 1) << 2;
             SUF(bind)(st, enc, ref, px, py, pu_w, pu_h, qp);
             int mvpx = c[0][0], mvpy = c[0][1];
             if (c[1][0] != c[0][0] || c[1][1] != c[0][1])
@@ -1184,7 +1199,7 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
                 out_mvp[2 * xy] = (int16_t)mvpx;
                 out_mvp[2 * xy + 1] = (int16_t)mvpy;
             }
-        }
+          }
     }
     free(st);
     return evals;

@@ -388,8 +388,13 @@ static inline void shim_clip(MV &mv, int picw, int pich, int px, int py)
     mv.y = (int16_t)X265_MIN(ymax, X265_MAX(ymin, (int)mv.y));
 }
 
-void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh,
-                  int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
+/* partMode 0: 2Nx2N PUs (every PU its own CU); 1: the parts of 2NxN CUs (puw x 2 puh), PU rows 2r / 2r + 1; 2: the parts of
+ * Nx2N CUs (2 puw x puh), PU columns 2c / 2c + 1.  CUs in raster order, parts one after the other (the partIdx loop, :2341);
+ * clipMv / xSetSearchRange from the CU's position; the upper part of a 2NxN CU takes candidate A from below-left (the lower
+ * part of the CU to the left: TComDataCU::fillMvpCand asks below-left before left, TComDataCU.cpp:2574-2588), the lower part
+ * has the upper part above it and nothing coded above-right. */
+void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh, int partMode,
+                        int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
 {
     RefME *r = (RefME*)h;
     r->me.setQP(qp);
@@ -400,18 +405,25 @@ void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, in
     r->planes.lumaStride = (int)stride;
     r->planes.isLowres = false;
     r->planes.lowresPlane[0] = ref;
-    const int gw = picw / puw, gh = pich / puh;
+    int gw = picw / puw, gh = pich / puh;
+    if (partMode == 1) gh &= ~1;
+    if (partMode == 2) gw &= ~1;
+    const int parts = partMode == 1 ? 2 : 1;
     MV *mvs = new MV[gw * gh];
     ALIGN_VAR_32(pixel, pred[64 * 64]);
     short *tmp = new short[64 * (64 + 7)];
-    for (int gy = 0; gy < gh; gy++)
+    for (int row = 0; row < gh / parts; row++)
     {
         for (int gx = 0; gx < gw; gx++)
-        {
+          for (int part = 0; part < parts; part++)
+          {
+            const int gy = row * parts + part;
+            const bool lower = part == 1;
             const int xy = gx + gy * gw, px = gx * puw, py = gy * puh;
+            const int cux = partMode == 2 ? (gx & ~1) * puw : px, cuy = partMode == 1 ? py - part * puh : py;
             const int puOffset = px + py * (int)stride;
             r->me.setSourcePU(puOffset, puw, puh);
-            const bool haveL = gx > 0, haveA = gy > 0, haveAR = gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
+            const bool haveL = gx > 0, haveA = gy > 0, haveAR = !lower && gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
             MV mvPredictors[3];                        // left, above, above-right (zero when absent)
             if (haveL)  mvPredictors[0] = mvs[xy - 1];
             if (haveA)  mvPredictors[1] = mvs[xy - gw];
@@ -421,7 +433,7 @@ void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, in
             if (haveAR) b = mvs[xy - gw + 1]; else if (haveA) b = mvs[xy - gw]; else if (haveAL) b = mvs[xy - gw - 1];
             if (haveL)
             {
-                cand[0] = mvs[xy - 1];
+                cand[0] = (partMode == 1 && !lower) ? mvs[xy + gw - 1] : mvs[xy - 1];
                 if (haveB && b != cand[0]) cand[1] = b;
             }
             else if (haveB)
@@ -433,7 +445,7 @@ void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, in
                 for (int i = 0; i < 2; i++)
                 {
                     MV mv = cand[i];
-                    shim_clip(mv, picw, pich, px, py);
+                    shim_clip(mv, picw, pich, cux, cuy);
                     pixel *src = ref + puOffset + (mv.x >> 2) + (mv.y >> 2) * stride;
                     int xFrac = mv.x & 3, yFrac = mv.y & 3;
                     unsigned cost;
@@ -463,11 +475,11 @@ void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, in
                 }
             }
             MV cmvp = mvp;
-            shim_clip(cmvp, picw, pich, px, py);
+            shim_clip(cmvp, picw, pich, cux, cuy);
             MV dist((int16_t)(merange << 2), (int16_t)(merange << 2));
             MV mvmin = cmvp - dist, mvmax = cmvp + dist;
-            shim_clip(mvmin, picw, pich, px, py);
-            shim_clip(mvmax, picw, pich, px, py);
+            shim_clip(mvmin, picw, pich, cux, cuy);
+            shim_clip(mvmax, picw, pich, cux, cuy);
             mvmin >>= 2;
             mvmax >>= 2;
             out_cost[xy] = r->me.motionEstimate(&r->planes, mvmin, mvmax, mvp, 3, mvPredictors, merange, mvs[xy]);
@@ -475,10 +487,16 @@ void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, in
             out_mv[2 * xy + 1] = mvs[xy].y;
             out_mvp[2 * xy] = mvp.x;
             out_mvp[2 * xy + 1] = mvp.y;
-        }
+          }
     }
     delete[] tmp;
     delete[] mvs;
+}
+
+void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh,
+                  int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
+{
+    ref_field_me_parts(h, enc, ref, stride, picw, pich, puw, puh, 0, merange, method, subme, qp, out_mv, out_cost, out_mvp);
 }
 
 /* bufSAD / bufSATD / bufSA8D of the cached PU (motion.h:89-93) */

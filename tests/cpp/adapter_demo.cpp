@@ -189,6 +189,70 @@ int main(int argc, char **argv)
             printf("chainstats %u %u %d\n", field.hits(), field.misses(), gw * gh);
             me.attachField(NULL);
         }
+        // (8) fields of several PU sizes and partition modes from ONE device call: the 2Nx2N fields of the 16x16 and 32x32 CUs and
+        //     the 2NxN / Nx2N fields of the 16x16 CUs.  For each an "encoder" that codes every CU in that mode walks the CUs in
+        //     raster order, part by part, derives the predictors from its own decisions by the rules of the partition mode and
+        //     calls motionEstimate at the unchanged call site.  One part per field is "coded intra".
+        {
+            typedef x265amd::MotionField::Shape Shape;
+            const std::vector<Shape> shapes = { Shape{ 16, 16, 0 }, Shape{ 32, 32, 0 }, Shape{ 16, 8, 1 }, Shape{ 8, 16, 2 } };
+            const int merange = 24;
+            x265amd::MotionField field(ctx);
+            me.setSearchMethod(1);
+            me.setSubpelRefine(3);
+            me.setQP(28);
+            field.runChained(pe, pr, shapes, merange, 1, 3, 28);
+            me.attachField(&field);
+            int total = 0;
+            for (size_t f = 0; f < shapes.size(); f++)
+            {
+                const Shape &sh = shapes[f];
+                int gw, gh;
+                x265amd::MotionField::shapeGrid(pe, sh, gw, gh);
+                const int parts = sh.part_mode == 1 ? 2 : 1;
+                std::vector<x265amd::MV> dec(gw * gh);
+                for (int row = 0; row < gh / parts; row++)
+                    for (int gx = 0; gx < gw; gx++)
+                        for (int part = 0; part < parts; part++)
+                        {
+                            const int gy = row * parts + part, xy = gx + gy * gw;
+                            const bool lower = part == 1;
+                            const int px = gx * sh.pu_w, py = gy * sh.pu_h;
+                            const int cuX = sh.part_mode == 2 ? (gx & ~1) * sh.pu_w : px, cuY = lower ? py - sh.pu_h : py;
+                            me.setSourcePUxy(px, py, sh.pu_w, sh.pu_h);
+                            const bool haveL = gx > 0, haveA = gy > 0, haveAR = !lower && gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
+                            x265amd::MV pred[3], cand[2], b;
+                            if (haveL) pred[0] = dec[xy - 1];
+                            if (haveA) pred[1] = dec[xy - gw];
+                            if (haveAR) pred[2] = dec[xy - gw + 1];
+                            const bool haveB = haveAR || haveA || haveAL;
+                            if (haveAR) b = dec[xy - gw + 1]; else if (haveA) b = dec[xy - gw]; else if (haveAL) b = dec[xy - gw - 1];
+                            // (upper part of a 2NxN CU: the left scan finds the below-left neighbour first)
+                            const x265amd::MV a = haveL ? ((sh.part_mode == 1 && !lower) ? dec[xy + gw - 1] : dec[xy - 1]) : x265amd::MV();
+                            if (haveL) { cand[0] = a; if (haveB && b != cand[0]) cand[1] = b; }
+                            else if (haveB) cand[0] = b;
+                            x265amd::MV mvp = cand[0];
+                            if (cand[1] != cand[0])
+                            {
+                                x265amd::MV cl[2] = { x265amd::clipMv(cand[0], W, H, cuX, cuY), x265amd::clipMv(cand[1], W, H, cuX, cuY) };
+                                int32_t t[2];
+                                me.mcCost(X265AMD_SAD, pr, cl, 2, t);
+                                if (t[1] < t[0]) mvp = cand[1];
+                            }
+                            x265amd::MV lo, hi, out;
+                            x265amd::setSearchRange(mvp, merange, W, H, cuX, cuY, lo, hi);
+                            int cost = me.motionEstimate(&pr, lo, hi, mvp, 3, pred, merange, out);
+                            const bool intra = xy == 21;
+                            dec[xy] = intra ? x265amd::MV(0, 0) : out;
+                            total++;
+                            printf("mchain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", sh.pu_w, sh.pu_h, sh.part_mode, gx, gy,
+                                   mvp.x, mvp.y, lo.x, lo.y, hi.x, hi.y, pred[0].x, pred[0].y, pred[1].x, pred[1].y, pred[2].x, pred[2].y,
+                                   out.x, out.y, cost, intra ? 1 : 0);
+                        }
+            }
+            printf("mchainstats %u %u %d\n", field.hits(), field.misses(), total);
+            me.attachField(NULL);
+        }
         ctx.releasePlane(pe);
         ctx.releasePlane(pr);
     }

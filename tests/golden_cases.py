@@ -262,3 +262,20 @@ def run_chain_suite(impl, bits: int) -> dict:
         out["mvp%d" % k] = np.ascontiguousarray(mvp)
     return out
 
+
+# the same for the parts of 2NxN (part_mode 1) and Nx2N (2) CUs: (pu_w, pu_h, part_mode, merange, method, subme, qp, content);
+# 208 x 120 leaves an odd PU row out of the 2NxN grids of 8- and 24-pixel-high parts
+CHAIN_PART_CASES = ((16, 8, 1, 24, J.HEX, 5, 30, "motion"), (8, 16, 2, 24, J.HEX, 5, 30, "motion"), (32, 16, 1, 16, J.STAR, 3, 36, "motion"),
+                    (16, 32, 2, 20, J.UMH, 2, 26, "noise"), (8, 4, 1, 12, J.DIA, 1, 33, "motion"), (4, 8, 2, 8, J.FULL, 0, 28, "motion"),
+                    (64, 32, 1, 32, J.HEX, 7, 31, "noise"), (32, 64, 2, 16, J.DIA, 4, 24, "motion"))
+
+
+def run_chain_parts_suite(impl, bits: int) -> dict:
+    """impl.field_run(enc, ref, pu_w, pu_h, merange, method, subme, qp, part_mode=m) -> (results[gh, gw], mvp[gh, gw, 2])"""
+    out = {}
+    for k, (pw, ph, pm, mr, method, subme, qp, kind) in enumerate(CHAIN_PART_CASES):
+        fr = chain_frames(bits, kind)
+        res, mvp = impl.field_run(fr[1], fr[0], pw, ph, mr, method, subme, qp, part_mode=pm)
+        out["res%d" % k] = np.ascontiguousarray(res)
+        out["mvp%d" % k] = np.ascontiguousarray(mvp)
+    return out

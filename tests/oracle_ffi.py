@@ -129,17 +129,20 @@ class Oracle:
         ref = self.make_plane(ref_padded, bit_depth, margin)
         return self.lib.meo_mc_cost(C.byref(enc), C.byref(ref), pu_x, pu_y, w, h, qx, qy, kind)
 
-    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN):
-        """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain"""
+    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN,
+                 part_mode: int = 0):
+        """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain
+        (part_mode 1 / 2: the parts of 2NxN / Nx2N CUs)"""
         enc = self.make_plane(enc_padded, bit_depth, margin)
         ref = self.make_plane(ref_padded, bit_depth, margin)
         pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
         gw, gh = pw // pu_w, ph // pu_h
+        gw, gh = (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
         out = np.zeros((gh, gw), dtype=RESULT_DTYPE)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)
-        self.lib.meo_field_me.restype = C.c_int64
-        ev = self.lib.meo_field_me(C.byref(enc), C.byref(ref), pw, ph, pu_w, pu_h, merange, method, subme, qp,
-                                   out.ctypes.data_as(C.c_void_p), mvp.ctypes.data_as(C.c_void_p))
+        self.lib.meo_field_me_parts.restype = C.c_int64
+        ev = self.lib.meo_field_me_parts(C.byref(enc), C.byref(ref), pw, ph, pu_w, pu_h, part_mode, merange, method, subme, qp,
+                                         out.ctypes.data_as(C.c_void_p), mvp.ctypes.data_as(C.c_void_p))
         return out, mvp, ev
 
     def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN, lowres=False):
@@ -259,19 +262,21 @@ class Reference:
         out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
         return out
 
-    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, margin: int = MARGIN):
+    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, margin: int = MARGIN, part_mode: int = 0):
         """(results[gh, gw], mvp[gh, gw, 2]): the reference's MotionEstimate driven over a PU grid with
-        predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me)"""
+        predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me_parts)"""
         pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
         gw, gh = pw // pu_w, ph // pu_h
+        gw, gh = (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
         mv = np.zeros((gh * gw, 2), dtype=np.int16)
         cost = np.zeros(gh * gw, dtype=np.int32)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)
         assert enc_padded.shape == ref_padded.shape
-        self.lib.ref_field_me.restype = None
-        self.lib.ref_field_me.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t] + [C.c_int] * 8 + [C.c_void_p] * 3
-        self.lib.ref_field_me(self.me, plane_origin(enc_padded, margin), plane_origin(ref_padded, margin), enc_padded.shape[1],
-                              pw, ph, pu_w, pu_h, merange, method, subme, qp, mv.ctypes.data, cost.ctypes.data, mvp.ctypes.data)
+        self.lib.ref_field_me_parts.restype = None
+        self.lib.ref_field_me_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t] + [C.c_int] * 9 + [C.c_void_p] * 3
+        self.lib.ref_field_me_parts(self.me, plane_origin(enc_padded, margin), plane_origin(ref_padded, margin), enc_padded.shape[1],
+                                    pw, ph, pu_w, pu_h, part_mode, merange, method, subme, qp, mv.ctypes.data, cost.ctypes.data,
+                                    mvp.ctypes.data)
         out = np.zeros(gh * gw, dtype=RESULT_DTYPE)
         out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
         return out.reshape(gh, gw), mvp

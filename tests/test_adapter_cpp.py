@@ -116,4 +116,19 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
         assert (int(l[15]), int(l[16]), int(l[17])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"])), l
     st = [int(v) for v in [l for l in lines if l[0] == "chainstats"][0][1:]]
     assert st[0] + st[1] == st[2] and st[0] >= 0.9 * st[2], st
-
+    # (8) fields of several PU sizes and partition modes from one device call, each behind its own walk of the CUs
+    rows = [l for l in lines if l[0] == "mchain"]
+    n_exp = (W // 16) * (H // 16) + (W // 32) * (H // 32) + 2 * (W // 16) * (H // 16) + 2 * (W // 16) * (H // 16)
+    assert len(rows) == n_exp
+    parts = []
+    for l in rows:
+        v = [int(t) for t in l[1:]]
+        jb = J.make_jobs(W, H, [v[3] * v[0]], [v[4] * v[1]], v[0], v[1], method=J.HEX, subme=3, merange=24, qp=28, qmvp=(v[5], v[6]),
+                         mvc=[[v[11], v[12]], [v[13], v[14]], [v[15], v[16]]])
+        jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = v[7], v[8], v[9], v[10]
+        parts.append(jb)
+    exp, _ = oracle.search(fr[0], [fr[1]], np.concatenate(parts), threads=4)
+    for l, ex in zip(rows, exp):
+        assert (int(l[18]), int(l[19]), int(l[20])) == (int(ex["mvx"]), int(ex["mvy"]), int(ex["cost"])), l
+    st = [int(v) for v in [l for l in lines if l[0] == "mchainstats"][0][1:]]
+    assert st[0] + st[1] == st[2] == n_exp and st[0] >= 0.9 * st[2], st

@@ -24,9 +24,12 @@ class GpuChain:
     def __init__(self, eng, bits):
         self.eng, self.depth = eng, 8 if bits == 8 else 10
 
-    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp):
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0):
         ids = [self.eng.upload_plane(enc, bit_depth=self.depth), self.eng.upload_plane(ref, bit_depth=self.depth)]
-        out = self.eng.field_me(ids[0], ids[1], pw, ph, mr, method, subme, qp)
+        if part_mode:
+            out = self.eng.field_me_multi([ids[0]], [ids[1]], [pw], [ph], [part_mode], mr, method, subme, qp)[0]
+        else:
+            out = self.eng.field_me(ids[0], ids[1], pw, ph, mr, method, subme, qp)
         for i in ids:
             self.eng.release_plane(i)
         return out
@@ -41,6 +44,49 @@ def test_predictor_chain_fields_match_reference_vectors(eng, bits):
     assert set(gold.files) == set(got.keys())
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_of_cu_parts_match_reference_vectors(eng, bits):
+    """the parts of 2NxN / Nx2N CUs (x265amd_field_me_multi's part modes) against the fixtures made by the compiled
+    reference under the same driver: 16x8 .. 64x32 and 4x8 parts, all five methods"""
+    gold = np.load(os.path.join(G.GOLDEN_DIR, "chain_parts_u%d.npz" % bits), allow_pickle=False)
+    got = G.run_chain_parts_suite(GpuChain(eng, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+def test_1080p_fields_of_every_depth_and_part_mode_in_one_call(eng, oracle):
+    """One call, one 1080p frame, a field per quadtree depth (64x64 .. 8x8) plus the 2NxN and Nx2N fields of the 16x16 and
+    32x32 CUs: every field equals the oracle's, the evaluation counts add up, and the call takes about as long as its
+    longest field (the 8x8 one) rather than the sum."""
+    import time
+    W, H = 1920, 1080
+    fr = synth.make_sequence(W, H, 2, seed=92)
+    ids = [eng.upload_plane(f) for f in fr]
+    shapes = [(8, 8, 0), (16, 16, 0), (32, 32, 0), (64, 64, 0), (16, 8, 1), (8, 16, 2), (32, 16, 1), (16, 32, 2)]
+    n = len(shapes)
+    args = ([ids[1]] * n, [ids[0]] * n, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes], 32, J.HEX, 3, 30)
+    eng.field_me_multi(*args)                       # (warm-up)
+    eng.eval_count(reset=True)
+    t0 = time.perf_counter()
+    got = eng.field_me_multi(*args)
+    t_all = time.perf_counter() - t0
+    total = 0
+    for (pw, ph, pm), (res, mvp) in zip(shapes, got):
+        exp, exp_mvp, evals = oracle.field_me(fr[1], fr[0], pw, ph, 32, J.HEX, 3, 30, part_mode=pm)
+        assert np.array_equal(res, exp), ((pw, ph, pm), np.argwhere(res != exp)[:5])
+        assert np.array_equal(mvp, exp_mvp), (pw, ph, pm)
+        total += evals
+    assert eng.eval_count() == total
+    t0 = time.perf_counter()
+    eng.field_me(ids[1], ids[0], 8, 8, 32, J.HEX, 3, 30)
+    t_8 = time.perf_counter() - t0
+    print("eight fields %.2f ms, the 8x8 field alone %.2f ms" % (1e3 * t_all, 1e3 * t_8))
+    assert t_all < 2.5 * t_8
+    for i in ids:
+        eng.release_plane(i)
 
 
 @pytest.mark.parametrize("pu,method,subme", [(16, J.HEX, 5), (64, J.STAR, 3), (8, J.HEX, 1)])

@@ -102,8 +102,8 @@ class OracleChain:
     def __init__(self, oracle, bits):
         self.o, self.depth = oracle, 8 if bits == 8 else 10
 
-    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp):
-        return self.o.field_me(enc, ref, pw, ph, mr, method, subme, qp, bit_depth=self.depth)[:2]
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0):
+        return self.o.field_me(enc, ref, pw, ph, mr, method, subme, qp, bit_depth=self.depth, part_mode=part_mode)[:2]
 
 
 @pytest.mark.parametrize("bits", [8, 16])
@@ -113,6 +113,17 @@ def test_predictor_chain_fields_match_reference_vectors(oracle, bits):
     reference's MotionEstimate and primitives under oracle/ref_shim.cpp's driver"""
     gold = _load("chain_u%d.npz" % bits)
     got = G.run_chain_suite(OracleChain(oracle, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_of_cu_parts_match_reference_vectors(oracle, bits):
+    """the same for the two parts of 2NxN and Nx2N CUs (CUs in raster order, their parts one after the other; bounds from
+    the CU's position; below-left candidate for the upper part, no above-right for the lower part of a 2NxN CU)"""
+    gold = _load("chain_parts_u%d.npz" % bits)
+    got = G.run_chain_parts_suite(OracleChain(oracle, bits), bits)
     assert set(gold.files) == set(got.keys())
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])

@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     L.x265amd_lookahead_status.argtypes = [vp]
     L.x265amd_field_me.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_me_batch.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.x265amd_field_me_multi.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_results_device.argtypes = [vp]
     L.x265amd_field_results_device.restype = vp
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
@@ -304,6 +305,38 @@ class Engine:
         self._chk(self.lib.x265amd_field_me_batch(self.h, len(enc), enc.ctypes.data, ref.ctypes.data, pu_w, pu_h, merange, method,
                                                   subme, qp, out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
         return (out, mvp) if fetch else None
+
+    @staticmethod
+    def field_grid(w: int, h: int, pu_w: int, pu_h: int, part_mode: int = 0):
+        """(PUs per row, PU rows) of a field: whole CUs only (part_mode 1 = 2NxN: CUs of pu_w x 2 pu_h, 2 = Nx2N: 2 pu_w x pu_h)"""
+        gw, gh = w // pu_w, h // pu_h
+        return (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
+
+    def field_me_multi(self, enc_planes, ref_planes, pu_w, pu_h, part_mode, merange: int, method: int, subme: int, qp: int,
+                       fetch: bool = True):
+        """fields of DIFFERENT PU sizes / partition modes in one call (one per quadtree depth, say), run side by side;
+        returns a list of (results[gh, gw], mvp[gh, gw, 2]) per field, or None with fetch=False"""
+        enc = np.ascontiguousarray(enc_planes, dtype=np.int32)
+        ref = np.ascontiguousarray(ref_planes, dtype=np.int32)
+        pw = np.ascontiguousarray(pu_w, dtype=np.int32)
+        ph = np.ascontiguousarray(pu_h, dtype=np.int32)
+        pm = np.ascontiguousarray(part_mode, dtype=np.int32)
+        assert len(enc) == len(ref) == len(pw) == len(ph) == len(pm) and len(enc) > 0
+        w, h = self.plane_geometry(int(enc[0]))[:2]
+        grids = [self.field_grid(w, h, int(a), int(b), int(m)) for a, b, m in zip(pw, ph, pm)]
+        n = sum(gw * gh for gw, gh in grids)
+        out = np.zeros(n, dtype=RESULT_DTYPE) if fetch else None
+        mvp = np.zeros((n, 2), dtype=np.int16) if fetch else None
+        self._chk(self.lib.x265amd_field_me_multi(self.h, len(enc), enc.ctypes.data, ref.ctypes.data, pw.ctypes.data, ph.ctypes.data,
+                                                  pm.ctypes.data, merange, method, subme, qp,
+                                                  out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
+        if not fetch:
+            return None
+        res, at = [], 0
+        for gw, gh in grids:
+            res.append((out[at:at + gw * gh].reshape(gh, gw), mvp[at:at + gw * gh].reshape(gh, gw, 2)))
+            at += gw * gh
+        return res
 
     # -- costs --------------------------------------------------------------------------------
     def cost_batch(self, kind: int, w: int, h: int, pairs: np.ndarray) -> np.ndarray:

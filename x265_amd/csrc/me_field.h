@@ -34,17 +34,30 @@
 
 namespace xa {
 
+// part_mode 0: every PU is the 2Nx2N PU of its own CU.  1 (2NxN): the CU is pu_w x 2 pu_h, PU rows 2r / 2r + 1 are its upper /
+// lower part; 2 (Nx2N): the CU is 2 pu_w x pu_h, PU columns 2c / 2c + 1 its left / right part.  CUs are coded in raster order, the
+// parts of a CU one after the other (the partIdx loop of predInterSearch, :2341), and what changes against part_mode 0 follows
+// from where the neighbour positions of TComDataCU::fillMvpCand (Lib/TLibCommon/TComDataCU.cpp:2553-2633) fall:
+//   * clipMv and xSetSearchRange use the CU's position, not the PU's (both parts of a CU share their bounds);
+//   * upper part of a 2NxN CU: its below-left neighbour is the lower part of the CU to the left, already coded, and the
+//     left candidate scan takes below-left before left - A = that PU's MV;
+//   * lower part of a 2NxN CU: above is the upper part of the same CU; above-right lies in the CU to the right, not coded
+//     yet - B = the upper part's MV, and the third start candidate is zero;
+//   * Nx2N: the neighbours are those of the uniform grid (the left part's left neighbour is the right part of the CU to
+//     the left, the right part's is the left part of its own CU).
+// With part_mode 1 one workgroup owns a CU row (two PU rows, walked upper part, lower part, next CU) and `gh` counts CU rows.
 template <class L>
 __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
                                                  int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
-                                                 int merange, int method, int subme, int qp, int flags,
+                                                 int merange, int method, int subme, int qp, int flags, int part_mode,
                                                  x265amd_me_result *out, int *out_mvp, int *error, unsigned long long *evals)
 {
     __shared__ __align__(16) L lds;
-    // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU rows of field f, top row first
-    const int field = (int)blockIdx.x / gh, gy = (int)blockIdx.x - field * gh;
-    out += (size_t)field * gw * gh;
-    out_mvp += (size_t)field * gw * gh;
+    // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU (CU) rows of field f, top row first
+    const int field = (int)blockIdx.x / gh, row = (int)blockIdx.x - field * gh;
+    const int parts = part_mode == 1 ? 2 : 1;                            // PU rows per workgroup
+    out += (size_t)field * gw * gh * parts;
+    out_mvp += (size_t)field * gw * gh * parts;
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
     {
         Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
@@ -54,19 +67,27 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
     const PlaneDesc &ref = planes[pairs[field].ref_plane];
     unsigned n_evals = 0;
     int failed = 0;
-    int left = 0;                                                        // MV word of the PU searched last
+    int last[2] = { 0, 0 };                                              // MV word of the PU to the left, per PU row of the workgroup
+    int cur_top = 0;                                                     // 2NxN: MV word of the upper part of the current CU
     Wave<L> W;
     W.sliced = false;
     auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };
 
     for (int gx = 0; gx < gw; gx++)
-    {
+#pragma nounroll
+      for (int part = 0; part < parts; part++)
+      {
+        const int gy = row * parts + part;
         const int px = gx * pu_w, py = gy * pu_h;
-        const bool have_l = gx > 0, have_a = gy > 0, have_ar = gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
+        const int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
+        const bool lower = part == 1;
+        const bool have_l = gx > 0, have_a = gy > 0, have_ar = !lower && gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
         // (the PU is cached while the row above may still be busy)
         W.bind(lds, enc, ref, px, py, px, py, pu_w, pu_h, cost, flags, true);
         int w_al = 0, w_a = 0, w_ar = 0;
-        if (have_a && !failed)
+        if (lower)
+            w_a = cur_top;                                              // (B = above exists: above-left is never asked for)
+        else if (have_a && !failed)
         {
             const x265amd_me_result *above = out + (size_t)(gy - 1) * gw + gx;
             const int v = LookLeaf::wait_mv3(above, (have_al ? 1 : 0) | 2 | (have_ar ? 4 : 0));
@@ -78,13 +99,15 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         auto mvx = [](int word) { return XA_S16(word & 0xffff); };
         auto mvy = [](int word) { return XA_S16(word >> 16); };
         // the two AMVP candidates
+        const int left = lower ? last[1] : last[0];                     // MV word of the PU to the left
+        const int wa_cand = parts == 2 ? last[1] : left;                // candidate A: 2NxN upper part - below-left, else left
         const int wb = have_ar ? w_ar : have_a ? w_a : w_al;
         const bool have_b = have_a;                                     // (above exists whenever any of the three does)
         int c0x = 0, c0y = 0, c1x = 0, c1y = 0;
         if (have_l)
         {
-            c0x = mvx(left); c0y = mvy(left);
-            if (have_b && wb != left)
+            c0x = mvx(wa_cand); c0y = mvy(wa_cand);
+            if (have_b && wb != wa_cand)
             {
                 c1x = mvx(wb); c1y = mvy(wb);
             }
@@ -93,9 +116,9 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         {
             c0x = mvx(wb); c0y = mvy(wb);
         }
-        // TComDataCU::clipMv for a CU at (px, py)
-        const int xmax = (pic_w + 8 - px - 1) << 2, xmin = (-max_cu - 8 - px + 1) << 2;
-        const int ymax = (pic_h + 8 - py - 1) << 2, ymin = (-max_cu - 8 - py + 1) << 2;
+        // TComDataCU::clipMv for a CU at (cux, cuy)
+        const int xmax = (pic_w + 8 - cux - 1) << 2, xmin = (-max_cu - 8 - cux + 1) << 2;
+        const int ymax = (pic_h + 8 - cuy - 1) << 2, ymin = (-max_cu - 8 - cuy + 1) << 2;
         W.ikind = X265AMD_SAD;
         int mvpx = c0x, mvpy = c0y;
         if (c1x != c0x || c1y != c0y)
@@ -128,11 +151,14 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         int ox, oy;
         const int c = S.run(nullptr, 0, ox, oy);
         n_evals += W.evals;
-        left = (oy << 16) | (ox & 0xffff);
+        const int word = (oy << 16) | (ox & 0xffff);
+        if (lower) last[1] = word; else last[0] = word;
+        if (!lower)
+            cur_top = word;
         if (out_mvp)
             LookLeaf::store_word(out_mvp + (size_t)gy * gw + gx, (mvpy << 16) | (mvpx & 0xffff));
         LookLeaf::publish(out + (size_t)gy * gw + gx, ox, oy, c);
-    }
+      }
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
 }

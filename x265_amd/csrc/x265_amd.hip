@@ -1991,51 +1991,65 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
 extern "C++" {
 namespace {
 template <typename PIX>
-void launch_field(x265amd_ctx *c, int cls, int n_fields, int gh, const uint16_t *cost, int pu_w, int pu_h, int gw,
-                  int pic_w, int pic_h, int merange, int method, int subme, int qp, x265amd_me_result *res, int *mvp, int *error)
+void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_fields, int gh, const uint16_t *cost, const LookPair *pairs, int pu_w, int pu_h,
+                  int gw, int pic_w, int pic_h, int merange, int method, int subme, int qp, int part_mode, x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_fields * gh), dim3(NW * 64), 0, c->stream, c->d_planes, cost, \
-                                              (const LookPair*)c->look_pairs.p, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_fields * gh), dim3(NW * 64), 0, st, c->d_planes, cost, \
+                                              pairs, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags, part_mode,   \
                                               res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
     else if (cls == 1) XA_FIELD(4, 256);
     else               XA_FIELD(8, 1024);
 #undef XA_FIELD
 }
+
+// PU grid of a field: PUs per row, PU rows (whole CUs only: an odd last PU row / column of a 2NxN / Nx2N grid is left out)
+bool field_grid(int pic_w, int pic_h, int pu_w, int pu_h, int part_mode, int &gw, int &gh)
+{
+    gw = pic_w / pu_w; gh = pic_h / pu_h;
+    if (part_mode == 1) gh &= ~1;
+    if (part_mode == 2) gw &= ~1;
+    return gw >= 1 && gh >= 1;
+}
 } // namespace
 } // extern "C++"
 
-int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, int pu_w, int pu_h, int merange,
-                           int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp)
+int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w, const int *pu_h,
+                           const int *part_mode, int merange, int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp)
 {
-    if (!c || n_fields < 1 || n_fields > 4096 || !enc_planes || !ref_planes)
+    if (!c || n_fields < 1 || n_fields > 4096 || !enc_planes || !ref_planes || !pu_w || !pu_h)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    if (!valid_dim(pu_w) || !valid_dim(pu_h) || method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 ||
-        qp < 0 || qp > 51 || merange < 0 || merange > 32767 || (method == X265AMD_UMH && pu_w == 4 && pu_h == 4))
+    if (method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 || qp < 0 || qp > 51 || merange < 0 || merange > 32767)
         return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
     std::vector<LookPair> hp(n_fields);
+    std::vector<size_t> first(n_fields + 1, 0);         // first result of field f
     for (int f = 0; f < n_fields; f++)
     {
+        const int pm = part_mode ? part_mode[f] : 0;
+        if (!valid_dim(pu_w[f]) || !valid_dim(pu_h[f]) || pm < 0 || pm > 2 || (method == X265AMD_UMH && pu_w[f] == 4 && pu_h[f] == 4) ||
+            (pm == 1 && 2 * pu_h[f] > 64) || (pm == 2 && 2 * pu_w[f] > 64))
+            return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
         const int refs[1] = { ref_planes[f] };
         if (int rc = check_batch_planes(c, enc_planes[f], refs, 1)) return rc;
-        const PlaneDesc &e = c->h_planes[enc_planes[f]], &r = c->h_planes[ref_planes[f]], &e0 = c->h_planes[enc_planes[0]];
-        if (e.lr_step || r.lr_step || e.width != r.width || e.height != r.height)
+        const PlaneDesc &ef = c->h_planes[enc_planes[f]], &r = c->h_planes[ref_planes[f]], &e0 = c->h_planes[enc_planes[0]];
+        if (ef.lr_step || r.lr_step || ef.width != r.width || ef.height != r.height)
             return fail(c, X265AMD_ERR_INVALID, "field search needs two full-resolution planes of one picture size");
-        if (e.width != e0.width || e.height != e0.height || e.bpp != e0.bpp)
+        if (ef.width != e0.width || ef.height != e0.height || ef.bpp != e0.bpp)
             return fail(c, X265AMD_ERR_INVALID, "the fields of one call must share picture size and pixel type");
         // clipMv lets a block reach 64 + 8 - 1 pixels beyond the picture; plus pattern overshoot and the filter apron
         if (r.margin_x < 71 + 3 + 4 || r.margin_y < 71 + 3 + 4)
             return fail(c, X265AMD_ERR_RANGE, "reference margins below 78 pixels");
         hp[f].enc_plane = enc_planes[f];
         hp[f].ref_plane = ref_planes[f];
+        int gw, gh;
+        if (!field_grid(ef.width, ef.height, pu_w[f], pu_h[f], pm, gw, gh))
+            return fail(c, X265AMD_ERR_INVALID, "picture smaller than one CU");
+        first[f + 1] = first[f] + (size_t)gw * gh;
     }
+    const size_t n = first[n_fields];
     const PlaneDesc &e = c->h_planes[enc_planes[0]];
-    const int gw = e.width / pu_w, gh = e.height / pu_h;
-    if (gw < 1 || gh < 1)
-        return fail(c, X265AMD_ERR_INVALID, "picture smaller than one PU");
-    const size_t n = (size_t)gw * gh * n_fields;
     if (int rc = sync_planes(c)) return rc;
     if (int rc = ensure(c, c->field_results, n * sizeof(x265amd_me_result))) return rc;
     if (int rc = ensure(c, c->field_mvp, n * sizeof(int))) return rc;
@@ -2048,14 +2062,75 @@ int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
-    const int cls = job_class(pu_w, pu_h);
-    if (e.bpp == 1)
-        launch_field<uint8_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
-                              (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p + ERR_WORD_FIELD);
-    else
-        launch_field<uint16_t>(c, cls, n_fields, gh, cost, pu_w, pu_h, gw, e.width, e.height, merange, method, subme, qp,
-                               (x265amd_me_result*)c->field_results.p, (int*)c->field_mvp.p, (int*)c->look_progress.p + ERR_WORD_FIELD);
-    HIPCHK(c, hipGetLastError());
+    // One launch per run of consecutive fields of one PU size and partition mode.  A field's time is the length of its chain, not
+    // its work, so the launches go to different streams and run side by side.
+    struct Run { int f0, f1; };
+    std::vector<Run> runs;
+    for (int f = 0; f < n_fields; f++)
+    {
+        const int pm = part_mode ? part_mode[f] : 0;
+        if (!runs.empty())
+        {
+            const int p = runs.back().f0;
+            if (pu_w[p] == pu_w[f] && pu_h[p] == pu_h[f] && (part_mode ? part_mode[p] : 0) == pm)
+            {
+                runs.back().f1 = f + 1;
+                continue;
+            }
+        }
+        runs.push_back({ f, f + 1 });
+    }
+    const int n_streams = (int)std::min<size_t>(runs.size(), x265amd_ctx::N_AUX + 1);
+    if (n_streams > 1)
+    {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int i = 0; i + 1 < n_streams; i++)
+            HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+    }
+    // (launches on one stream run one after the other: the runs go, longest chain first, to the stream with the least queued;
+    // a chain's length in PU steps is a row's PUs plus the two-CU lag of every further row, and a step takes about
+    // 12 + 0.75 sqrt(PU area) microseconds - measured 16 us at 8x8, 24 at 16x16, 39 at 32x32, 62 at 64x64)
+    std::vector<int> by_len(runs.size()), stream_of(runs.size());
+    std::vector<long> len(runs.size()), load(n_streams, 0);
+    for (size_t k = 0; k < runs.size(); k++)
+    {
+        const int f0 = runs[k].f0, pm = part_mode ? part_mode[f0] : 0;
+        int gw, gh;
+        field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
+        const int parts = pm == 1 ? 2 : 1;
+        len[k] = (long)(parts * (gw + 2 * (gh / parts)) * (12.0 + 0.75 * sqrt((double)pu_w[f0] * pu_h[f0])));
+        by_len[k] = (int)k;
+    }
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return len[a] > len[b]; });
+    for (int k : by_len)
+    {
+        const int s = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        stream_of[k] = s;
+        load[s] += len[k];
+    }
+    for (int k : by_len)
+    {
+        const int f0 = runs[k].f0, nf = runs[k].f1 - f0, pm = part_mode ? part_mode[f0] : 0;
+        int gw, gh;
+        field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
+        hipStream_t st = stream_of[k] == 0 ? c->stream : c->aux[stream_of[k] - 1];
+        const int cls = job_class(pu_w[f0], pu_h[f0]);
+        const int wg_rows = pm == 1 ? gh / 2 : gh;
+        x265amd_me_result *res = (x265amd_me_result*)c->field_results.p + first[f0];
+        int *mvp = (int*)c->field_mvp.p + first[f0];
+        const LookPair *pairs = (const LookPair*)c->look_pairs.p + f0;
+        int *err = (int*)c->look_progress.p + ERR_WORD_FIELD;
+        if (e.bpp == 1)
+            launch_field<uint8_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, res, mvp, err);
+        else
+            launch_field<uint16_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, res, mvp, err);
+        HIPCHK(c, hipGetLastError());
+    }
+    for (int i = 0; i + 1 < n_streams; i++)
+    {
+        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+    }
     if (c->timing)
     {
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -2075,6 +2150,15 @@ int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, 
         return fail(c, X265AMD_ERR_HIP, "field search: a PU row waited too long for the row above it");
     }
     return 0;
+}
+
+int x265amd_field_me_batch(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, int pu_w, int pu_h, int merange,
+                           int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp)
+{
+    if (n_fields < 1 || n_fields > 4096)
+        return X265AMD_ERR_INVALID;
+    const std::vector<int> w(n_fields, pu_w), h(n_fields, pu_h);
+    return x265amd_field_me_multi(c, n_fields, enc_planes, ref_planes, w.data(), h.data(), nullptr, merange, method, subme, qp, out, out_mvp);
 }
 
 int x265amd_field_me(x265amd_ctx *c, int enc_plane, int ref_plane, int pu_w, int pu_h, int merange, int method, int subme, int qp,

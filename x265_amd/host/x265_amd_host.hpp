@@ -227,6 +227,68 @@ public:
         m_enc = enc.plane_id;
         m_valid = true;
     }
+    // One field per entry of `shapes` - a PU size and a partition mode each (x265amd_field_me_multi): the 2Nx2N fields of
+    // several quadtree depths and the 2NxN / Nx2N fields beside them, searched side by side in ONE device call and entered
+    // under the arguments predInterSearch would pass for each part (bounds from the CU's position).
+    struct Shape { int pu_w, pu_h, part_mode; };
+    static void shapeGrid(const ReferencePlanes &enc, const Shape &s, int &gw, int &gh)
+    {
+        gw = enc.width / s.pu_w; gh = enc.height / s.pu_h;
+        if (s.part_mode == 1) gh &= ~1;
+        if (s.part_mode == 2) gw &= ~1;
+    }
+    void runChained(const ReferencePlanes &enc, const ReferencePlanes &ref, const std::vector<Shape> &shapes, int merange, int method,
+                    int subme, int qp)
+    {
+        const int nf = (int)shapes.size();
+        std::vector<int> encs(nf, enc.plane_id), refids(nf, ref.plane_id), pw(nf), ph(nf), pm(nf);
+        std::vector<size_t> first(nf + 1, 0);
+        for (int f = 0; f < nf; f++)
+        {
+            int gw, gh;
+            shapeGrid(enc, shapes[f], gw, gh);
+            pw[f] = shapes[f].pu_w; ph[f] = shapes[f].pu_h; pm[f] = shapes[f].part_mode;
+            first[f + 1] = first[f] + (size_t)gw * gh;
+        }
+        std::vector<x265amd_me_result> all(first[nf]);
+        std::vector<int16_t> allmvp(first[nf] * 2);
+        m_ctx.check(x265amd_field_me_multi(m_ctx.get(), nf, encs.data(), refids.data(), pw.data(), ph.data(), pm.data(), merange, method,
+                                           subme, qp, all.data(), allmvp.data()));
+        if (m_valid && m_enc != enc.plane_id)
+            clear();
+        for (int f = 0; f < nf; f++)
+        {
+            const Shape &sh = shapes[f];
+            int gw, gh;
+            shapeGrid(enc, sh, gw, gh);
+            const x265amd_me_result *res = all.data() + first[f];
+            const int16_t *mvp = allmvp.data() + first[f] * 2;
+            for (int gy = 0; gy < gh; gy++)
+                for (int gx = 0; gx < gw; gx++)
+                {
+                    const int xy = gx + gy * gw;
+                    const bool lower = sh.part_mode == 1 && (gy & 1);
+                    x265amd_me_job j = x265amd_me_job();
+                    j.pu_x = gx * sh.pu_w; j.pu_y = gy * sh.pu_h; j.w = (int16_t)sh.pu_w; j.h = (int16_t)sh.pu_h;
+                    const int cuX = sh.part_mode == 2 ? (gx & ~1) * sh.pu_w : j.pu_x, cuY = lower ? j.pu_y - sh.pu_h : j.pu_y;
+                    MV p(mvp[2 * xy], mvp[2 * xy + 1]), lo, hi;
+                    setSearchRange(p, merange, enc.width, enc.height, cuX, cuY, lo, hi);
+                    j.mvmin_x = lo.x; j.mvmin_y = lo.y; j.mvmax_x = hi.x; j.mvmax_y = hi.y;
+                    j.qmvp_x = p.x; j.qmvp_y = p.y;
+                    j.merange = (int16_t)merange; j.method = (uint8_t)method; j.subme = (uint8_t)subme; j.qp = (uint8_t)qp;
+                    j.numc = 3; j.icost = X265AMD_SAD;
+                    if (gx > 0)                          { j.mvc[0][0] = res[xy - 1].mvx;      j.mvc[0][1] = res[xy - 1].mvy; }
+                    if (gy > 0)                          { j.mvc[1][0] = res[xy - gw].mvx;     j.mvc[1][1] = res[xy - gw].mvy; }
+                    if (!lower && gy > 0 && gx + 1 < gw) { j.mvc[2][0] = res[xy - gw + 1].mvx; j.mvc[2][1] = res[xy - gw + 1].mvy; }
+                    const int at = add(ref, j);
+                    if ((size_t)at >= m_results.size())
+                        m_results.resize(at + 1);
+                    m_results[at] = res[xy];
+                }
+        }
+        m_enc = enc.plane_id;
+        m_valid = true;
+    }
     // the stored result of a request identical to a planned one
     bool lookup(const ReferencePlanes &enc, const ReferencePlanes &ref, x265amd_me_job want, x265amd_me_result &out)
     {
