@@ -480,6 +480,56 @@ def test_device_resident_and_planned_paths_agree(eng, oracle):
         eng.release_plane(i)
 
 
+def test_device_resident_full_frame_is_bundled_on_the_device(eng, oracle):
+    """A 1080p FULL +-64 frame (all four square PU levels, a predictor per cell and - second list - per PU) handed over as
+    a raw device array: the bundles of the shared-window pass are formed on the device, the results equal the planned
+    list's and a sample of the oracle's, and the call takes at most 1.2 x the planned list's time (1.3 x with a predictor
+    per PU)."""
+    import time
+    import torch
+    W, H = 1920, 1080
+    fr = synth.make_sequence(W, H, 2, seed=77)
+    ids = [eng.upload_plane(f) for f in fr]
+    rng = np.random.default_rng(12)
+    dev = torch.device("cuda", 0)
+    for spread in (0, 5):
+        parts = []
+        cells = rng.integers(-16, 17, size=(32 * 17, 2))
+        for s in (64, 32, 16, 8):
+            x, y = J.square_pu_grid(W, H, s)
+            q = cells[(y // 64) * 32 + x // 64] + (rng.integers(-spread, spread + 1, size=(x.size, 2)) if spread else 0)
+            parts.append(J.make_jobs(W, H, x, y, s, s, method=J.FULL, subme=0, merange=64, qp=32,
+                                     qmvp=(q[:, 0].astype(np.int16), q[:, 1].astype(np.int16))))
+        jobs = np.concatenate(parts)
+        jl = eng.make_joblist(jobs)
+        b = jl.run(ids[0], [ids[1]])
+        dj = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
+        do = torch.zeros(len(jobs) * 8, dtype=torch.uint8, device=dev)
+        eng.search_device(ids[0], [ids[1]], dj.data_ptr(), len(jobs), do.data_ptr())
+        eng.sync()
+        c = do.cpu().numpy().view(J.RESULT_DTYPE)
+        assert np.array_equal(c, b), (spread, np.nonzero(c != b)[0][:5])
+        sel = np.arange(0, len(jobs), 97)
+        exp, _ = oracle.search(fr[0], [fr[1]], jobs[sel], threads=8)
+        assert np.array_equal(c[sel], exp), spread
+        t_list, t_dev = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            jl.run(ids[0], [ids[1]], fetch=False)
+            eng.sync()
+            t_list.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            eng.search_device(ids[0], [ids[1]], dj.data_ptr(), len(jobs), do.data_ptr())
+            eng.sync()
+            t_dev.append(time.perf_counter() - t0)
+        print("spread %d: planned list %.3f ms, device array %.3f ms" % (spread, 1e3 * min(t_list), 1e3 * min(t_dev)))
+        # (a predictor per PU: the device planner keeps a cell's PUs in one bundle where the host planner may split them)
+        assert min(t_dev) <= (1.2 if spread == 0 else 1.3) * min(t_list), (spread, min(t_dev), min(t_list))
+        jl.close()
+    for i in ids:
+        eng.release_plane(i)
+
+
 @pytest.mark.parametrize("bits,depth", [(8, 8), (16, 10)])
 def test_large_pus_alone_and_beside_small_pus(eng, oracle, bits, depth):
     """PUs of more than 1024 pixels run on eight wavefronts when their launch has the GPU to itself and on four

@@ -568,44 +568,80 @@ __global__ void __launch_bounds__(FULL_THREADS) k_full_items(BatchParams P, cons
                                                              FullBest *fb, int fb_stride, int lds_dwords)
 {
     extern __shared__ __align__(16) uint32_t lds[];
-    int id = blockIdx.x;
-    if (id >= n_items)
-        return;
-    const FullItem &it = items[id];
-    if (it.count <= 0)
-        return;
     if (W4 != 0)
     {
+        const int id = blockIdx.x;
+        if (id >= n_items)
+            return;
+        const FullItem &it = items[id];
+        if (it.count <= 0)
+            return;
         full_item_body<W4 ? W4 : 1, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords);
         return;
     }
-    const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
-    switch (j0.w >> 2)
+    // (one item per job, most of them possibly empty: a bounded number of workgroups takes a stretch of the list each, so that
+    // an empty item costs a lane of one load and not a workgroup with the full LDS allocation; every wavefront looks at the
+    // stretch's items 256 at a time - four per lane - and all of them walk the non-empty ones together)
+    const int per = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int end = min(n_items, ((int)blockIdx.x + 1) * per), lane = threadIdx.x & 63;
+    for (int c0 = (int)blockIdx.x * per; c0 < end; c0 += 256)
     {
-    case 1:  full_item_body<1, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 2:  full_item_body<2, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 3:  full_item_body<3, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 4:  full_item_body<4, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 6:  full_item_body<6, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 8:  full_item_body<8, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 12: full_item_body<12, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    case 16: full_item_body<16, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
-    default: break;
+        unsigned long long mask[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int id = c0 + 64 * r + lane;
+            mask[r] = __ballot(id < end && items[id].count > 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            while (mask[r])
+            {
+                const int id = c0 + 64 * r + __builtin_ctzll(mask[r]);
+                mask[r] &= mask[r] - 1;
+                const FullItem &it = items[id];
+                const x265amd_me_job &j0 = jobs[item_jobs[it.first]];
+                switch (j0.w >> 2)
+                {
+                case 1:  full_item_body<1, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 2:  full_item_body<2, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 3:  full_item_body<3, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 4:  full_item_body<4, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 6:  full_item_body<6, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 8:  full_item_body<8, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 12: full_item_body<12, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                case 16: full_item_body<16, PIX>(P, jobs, item_jobs, it, fb, fb_stride, lds, lds_dwords); break;
+                default: break;
+                }
+                __syncthreads();        // (the next item reuses the LDS)
+            }
     }
 }
 
 // One item per job, built on the device: used when the job array only exists in device memory
 // and no plan was made for it.  Ineligible jobs get an empty item.
-__global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, int *item_jobs, FullItem *items)
+// `skip` (optional): jobs whose scan the hierarchical kernel has run for bundles formed on the device (me_plan.h); their
+// slot of `keys` holds the winner as cost << 32 | (mvy + 32768) << 16 | (mvx + 32768) and becomes a FullBest here.
+__global__ void k_make_items(BatchParams P, const x265amd_me_job *jobs, int n, int *item_jobs, FullItem *items, const unsigned char *skip,
+                             unsigned long long *keys)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n)
         return;
+    if (skip && skip[id])
+    {
+        const unsigned long long k = keys[id];
+        FullBest f;
+        f.cost = k == ~0ull ? 0x7fffffff : (int)(k >> 32);
+        f.mvx = k == ~0ull ? 0 : (int16_t)((int)(k & 0xffff) - 32768);
+        f.mvy = k == ~0ull ? 0 : (int16_t)((int)((k >> 16) & 0xffff) - 32768);
+        ((FullBest*)keys)[id] = f;
+    }
     const x265amd_me_job &j = jobs[id];
     FullItem it;
     it.first = id;
     item_jobs[id] = id;
-    it.count = job_fields_valid(j, P.n_refs) && full_kernel_eligible(j, P.planes[P.enc_plane].bpp) ? 1 : 0;
+    it.count = job_fields_valid(j, P.n_refs) && full_kernel_eligible(j, P.planes[P.enc_plane].bpp) && !(skip && skip[id]) ? 1 : 0;
     const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
     const int XG = (nx + 3) >> 2, XGe = XG + (XG & 1), W4 = j.w >> 2;
     const int ND = (XGe + W4) * P.planes[P.enc_plane].bpp;      // dwords per window row

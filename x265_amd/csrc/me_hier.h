@@ -69,6 +69,9 @@ struct HierBundle
     // rect_end[20]: PUs made of 16x16 values of the whole cell.  rect_end[g] = end of group g in rect[].
     int32_t  rect_end[21];
     int32_t  quads;             // me_had.h only: the bundle has PUs with 4- or 12-pixel sides (their jobs: HierQuads of this bundle)
+    // bundles formed on the device (me_plan.h): work items (slabs) of the bundle, lane tasks per work item, LDS row pitch and
+    // the LDS bytes its largest work item needs; n_slabs = 0: this cell of the planner's table holds no bundle
+    int32_t  n_slabs, per, pitch, lds_need;
     struct Rect { int32_t job; uint32_t kind; } rect[HIER_MAX_RECT];
 };
 
@@ -112,6 +115,8 @@ __global__ void __launch_bounds__(256) k_pack_fenc(BatchParams P, const HierBund
         return;
     const PlaneDesc &enc = P.planes[P.enc_plane];
     const HierBundle &B = bundles[b];
+    if (B.nxw <= 0)         // (a cell of the device planner's table that holds no bundle)
+        return;
     const uint8_t *org = (const uint8_t*)enc.origin;
     for (int i = threadIdx.x; i < HIER_FENC_DW; i += 256)
     {
@@ -293,6 +298,25 @@ __device__ __forceinline__ void hier_job_mask(const x265amd_me_job *jobs, int ji
     }
 }
 
+// Bundles formed on the device (me_plan.h): bundle c is cell c of the picture's cell table and has n_slabs <= PLAN_SLABS work
+// items; offsets[c] = work items of the cells before c (offsets[n_cells] = all of them).  The launch covers
+// n_cells x PLAN_SLABS workgroups; workgroup b takes work item plan_item_of_block(b, total) - the XCD-interleaved order of the
+// planned lists (xcd_interleave in x265_amd.hip: 8 * PLAN_BANDS bands of consecutive work items, XCD b % 8 takes bands x,
+// x + 8, ... in turn) - and the workgroups beyond the last work item, all at the end of the launch, leave at once.
+constexpr int PLAN_SLABS = 16;              // most work items per bundle (= FB_STRIDE_PLAN of the host planner)
+// LDS size classes of the launches over device-formed bundles (a bundle runs in the smallest class that holds its largest
+// work item): 8, 6 and 4 workgroups per CU.  1080p +-64 needs 19904 bytes with one predictor, about 26 K with one per PU.
+constexpr int PLAN_LDS_CLASSES = 3;
+__device__ __host__ constexpr int plan_lds_class(int k) { return k == 0 ? 19968 : k == 1 ? 27136 : 40960; }
+constexpr int PLAN_BANDS = 2;
+__device__ __forceinline__ int plan_item_of_block(int b, int total)
+{
+    const int per = (total + 8 * PLAN_BANDS - 1) / (8 * PLAN_BANDS);
+    const int x = b & 7, t = b >> 3, g = t / per, k = t - g * per;
+    const int i = (g * 8 + x) * per + k;
+    return g < PLAN_BANDS && i < total ? i : -1;
+}
+
 // What hier_item_body keeps in LDS per PU of a bundle with several predictors
 struct HierPredPu
 {
@@ -339,7 +363,7 @@ __device__ __forceinline__ unsigned long long hier_lane_min64_pred(const uint32_
 
 // MODE 0: one predictor, every job's range is the window; 1: one predictor, per-job ranges; 2: per-job predictors, every job's
 // range is the same around its predictor; 3: per-job predictors and ranges
-template <int MODE>
+template <int MODE, bool KEYS>
 __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265amd_me_job *jobs, const HierBundle &B, const HierItem &it,
                                                const XA_CONST uint32_t *pf, FullBest *fb, int fb_stride, uint32_t *lds)
 {
@@ -675,16 +699,65 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             f.cost = cost;
             f.mvx = ridx < 0 ? 0 : (int16_t)(B.mvx0 + ridx % nxw);
             f.mvy = ridx < 0 ? 0 : (int16_t)(B.mvy0 + ridx / nxw);
-            fb[(size_t)jid * fb_stride + it.slot] = f;
+            if (KEYS)
+            {
+                // one key per job for all slabs: cost, then raster order of the MV (what combine_slabs picks among slab slots)
+                if (ridx >= 0)
+                    atomicMin((unsigned long long*)(fb + (size_t)jid * fb_stride),
+                              ((unsigned long long)(uint32_t)cost << 32) | ((uint32_t)(f.mvy + 32768) << 16) | (uint32_t)(f.mvx + 32768));
+            }
+            else
+                fb[(size_t)jid * fb_stride + it.slot] = f;
         }
     }
 }
 
+// KEYS = false: the work items of a planned list, results in one FullBest slot per (job, slab).  KEYS = true: bundles
+// formed on the device - `items` is the offsets array described above, n_items the number of cells, a job's slabs meet in
+// one 64-bit key, and fb_stride = -(LDS size class of this launch, plan_lds_class): every class has a launch of its own.
+template <bool KEYS>
 __global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                             const HierItem *items, int n_items, const uint32_t *packed,
                                                             FullBest *fb, int fb_stride)
 {
     extern __shared__ __align__(16) uint32_t lds[];
+    if (KEYS)
+    {
+        const int *offsets = (const int*)items;
+        const int id = plan_item_of_block(blockIdx.x, offsets[n_items]);
+        if (id < 0)
+            return;
+        int lo = 0, hi = n_items;               // the cell with offsets[cell] <= id < offsets[cell + 1]
+        while (hi - lo > 1)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= id) lo = mid; else hi = mid;
+        }
+        const HierBundle &B = bundles[lo];
+        const int cls = -fb_stride;             // this launch's LDS class
+        if (B.lds_need > plan_lds_class(cls) || (cls > 0 && B.lds_need <= plan_lds_class(cls - 1)))
+            return;
+        const int XG = (B.nxw + 3) >> 2, ntasks = ((B.nyw + HIER_R - 1) / HIER_R) * XG;
+        HierItem it;
+        it.bundle = lo;
+        it.t_lo = (id - offsets[lo]) * B.per;
+        it.t_hi = it.t_lo + B.per < ntasks ? it.t_lo + B.per : ntasks;
+        it.slot = 0;
+        it.pitch = B.pitch;
+        it.win_nd = XG + 16;
+        it.win_rows = ((it.t_hi - 1) / XG - it.t_lo / XG + 1) * HIER_R + 63;
+        it.pad = 0;
+        const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)lo * HIER_FENC_DW);
+        if (B.pred == 1)
+            hier_item_body<2, true>(P, jobs, B, it, pf, fb, 1, lds);
+        else if (B.pred)
+            hier_item_body<3, true>(P, jobs, B, it, pf, fb, 1, lds);
+        else if (B.uniform)
+            hier_item_body<0, true>(P, jobs, B, it, pf, fb, 1, lds);
+        else
+            hier_item_body<1, true>(P, jobs, B, it, pf, fb, 1, lds);
+        return;
+    }
     const int id = blockIdx.x;
     if (id >= n_items)
         return;
@@ -692,13 +765,13 @@ __global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const
     const HierBundle &B = bundles[it.bundle];
     const XA_CONST uint32_t *pf = (const XA_CONST uint32_t*)(uintptr_t)(packed + (size_t)it.bundle * HIER_FENC_DW);
     if (B.pred == 1)
-        hier_item_body<2>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        hier_item_body<2, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else if (B.pred)
-        hier_item_body<3>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        hier_item_body<3, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else if (B.uniform)
-        hier_item_body<0>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        hier_item_body<0, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
     else
-        hier_item_body<1>(P, jobs, B, it, pf, fb, fb_stride, lds);
+        hier_item_body<1, false>(P, jobs, B, it, pf, fb, fb_stride, lds);
 }
 
 } // namespace xa

@@ -3,6 +3,7 @@
 #include "me_kernels.h"
 #include "me_full.h"
 #include "me_hier.h"
+#include "me_plan.h"
 #include "me_had.h"
 #include "me_lowres.h"
 #include "me_field.h"
@@ -103,7 +104,7 @@ struct x265amd_ctx
     uint16_t    *d_cost = nullptr;        // 52 x 65536
     unsigned long long *d_evals = nullptr;   // EVAL_SLOTS counters 16 words apart (+ 16 words of developer counters)
 
-    DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress;
+    DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress, plan_mem;
     DevBuf field_results, field_mvp;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
@@ -422,7 +423,10 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
         }
     }
     // with index lists every launch has work: run the classes side by side
-    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0) + (cnt[4] > 0)) : 1;
+    // (without them every launch visits all jobs and most workgroups leave at once: side by side as well, so that the
+    // few long ones of the large-PU class do not hold up the rest)
+    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0) + (cnt[4] > 0))
+                               : (n >= 4096 ? c->n_lanes : 1);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     bool lr = false;
@@ -453,16 +457,57 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
 // call reads is written earlier in the same call (k_make_items fills all items and indices; the exhaustive
 // kernel writes the FullBest of every job it is eligible for, and only those are read), so the buffers
 // need no clearing and may hold an earlier call's contents.
+// plan_mem (optional): memory for the device-side planner of me_plan.h (plan_bytes(cells, n) bytes, 256-byte aligned) for
+// the picture's cells_x x cells_y 64x64 cells per reference plane.  With it the square FULL-search SAD jobs of a cell on
+// 8-bit planes share the hierarchical kernel's pass, as in a planned list; what the planner leaves out is scanned job by job.
+size_t plan_bytes(int n_cells, int n)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(4 * (size_t)n_cells * HIER_PUS) + up(sizeof(HierBundle) * (size_t)n_cells) +
+           up(4 * ((size_t)n_cells + 1)) + up((size_t)HIER_FENC_DW * 4 * n_cells) + up((size_t)n);
+}
+
 int launch_search_unplanned(x265amd_ctx *c, const BatchParams &P, int bpp, const x265amd_me_job *d_jobs, int n,
-                            x265amd_me_result *d_out, FullBest *fb, FullItem *items, int *item_jobs)
+                            x265amd_me_result *d_out, FullBest *fb, FullItem *items, int *item_jobs,
+                            unsigned char *plan_mem = nullptr, int cells_x = 0, int cells_y = 0)
 {
     if (int rc = record_start(c)) return rc;
-    hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n, item_jobs, items);
+    const unsigned char *skip = nullptr;
+    if (plan_mem && bpp == 1 && c->hier_ok && !(c->flags & 16))
+    {
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        DevPlan D;
+        D.cells_x = cells_x; D.cells_y = cells_y; D.n_cells = cells_x * cells_y * P.n_refs;
+        unsigned char *p = plan_mem;
+        D.slots = (uint32_t*)p;        p += up(4 * (size_t)D.n_cells * HIER_PUS);
+        D.bundles = (HierBundle*)p;    p += up(sizeof(HierBundle) * (size_t)D.n_cells);
+        D.offsets = (int32_t*)p;       p += up(4 * ((size_t)D.n_cells + 1));
+        uint32_t *fenc = (uint32_t*)p; p += up((size_t)HIER_FENC_DW * 4 * D.n_cells);
+        D.in_bundle = p;
+        D.keys = (unsigned long long*)fb;
+        static_assert(sizeof(FullBest) == sizeof(unsigned long long), "a job's key lives in its FullBest");
+        const int jb = (n + 255) / 256;
+        hipLaunchKernelGGL(k_plan_clear, dim3(std::min(1024, std::max(jb, (D.n_cells * HIER_PUS + 255) / 256))), dim3(256), 0, c->stream, D, n);
+        hipLaunchKernelGGL(k_plan_slots, dim3(jb), dim3(256), 0, c->stream, P, D, d_jobs, n);
+        hipLaunchKernelGGL(k_plan_bundles, dim3(D.n_cells), dim3(64), 0, c->stream, P, D, d_jobs, plan_lds_class(PLAN_LDS_CLASSES - 1));
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, c->stream, D);
+        hipLaunchKernelGGL(k_pack_fenc, dim3(D.n_cells), dim3(256), 0, c->stream, P, (const HierBundle*)D.bundles, D.n_cells, fenc);
+        // (one launch per LDS size class over all work items; a workgroup whose bundle belongs to another class leaves at once)
+        for (int k = 0; k < PLAN_LDS_CLASSES; k++)
+            hipLaunchKernelGGL(k_full_hier<true>, dim3(D.n_cells * PLAN_SLABS), dim3(HIER_THREADS), plan_lds_class(k), c->stream, P, d_jobs,
+                               (const HierBundle*)D.bundles, (const HierItem*)D.offsets, D.n_cells, (const uint32_t*)fenc, fb, -k);
+        HIPCHK(c, hipGetLastError());
+        skip = D.in_bundle;
+    }
+    hipLaunchKernelGGL(k_make_items, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, d_jobs, n, item_jobs, items, skip,
+                       (unsigned long long*)fb);
+    // (two workgroups with the full LDS allocation fit a CU; four rounds of them even out items of different length)
+    const int full_grid = std::min(n, 2048);
     if (bpp == 1)
-        hipLaunchKernelGGL((k_full_items<0, uint8_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+        hipLaunchKernelGGL((k_full_items<0, uint8_t>), dim3(full_grid), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
                            (const int*)item_jobs, (const FullItem*)items, n, fb, 1, FULL_LDS_MAX / 4);
     else
-        hipLaunchKernelGGL((k_full_items<0, uint16_t>), dim3(n), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
+        hipLaunchKernelGGL((k_full_items<0, uint16_t>), dim3(full_grid), dim3(FULL_THREADS), FULL_LDS_MAX, c->stream, P, d_jobs,
                            (const int*)item_jobs, (const FullItem*)items, n, fb, 1, FULL_LDS_MAX / 4);
     HIPCHK(c, hipGetLastError());
     c->timed_full = true;
@@ -1249,7 +1294,7 @@ int joblist_launch_full(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P
         hipStream_t st = c->lane(k++);
         hipLaunchKernelGGL(k_pack_fenc, dim3(L->n_hier_bundles), dim3(256), 0, st, P, (const HierBundle*)L->hier_bundles.p,
                            L->n_hier_bundles, (uint32_t*)L->hier_fenc.p);
-        hipLaunchKernelGGL(k_full_hier, dim3(L->n_hier_items), dim3(HIER_THREADS), L->hier_lds_bytes, st, P,
+        hipLaunchKernelGGL(k_full_hier<false>, dim3(L->n_hier_items), dim3(HIER_THREADS), L->hier_lds_bytes, st, P,
                            (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->hier_bundles.p,
                            (const HierItem*)L->hier_items.p, L->n_hier_items, (const uint32_t*)L->hier_fenc.p,
                            (FullBest*)L->fb.p, FB_STRIDE_PLAN);
@@ -1338,7 +1383,7 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 
 // ---- scratch of the allocation-free entry point (x265amd_me_search_batch_device_noalloc) ------------
 // One FullBest, one FullItem and one item-job index per job, for up to NOALLOC_MAX_JOBS jobs, in a
-// file-scope device array: every GPU the library runs on holds its own copy (3.25 MiB) at its own
+// file-scope device array: every GPU the library runs on holds its own copy (3.25 MiB, and 6.2 MiB of planner tables) at its own
 // address until the process ends.  `scratch` is only a host-side stand-in for the symbol: the device
 // address is looked up once per device (resolve_scratch, called by x265amd_create with that device
 // current) and only that address is ever handed to kernels.
@@ -1346,7 +1391,14 @@ constexpr int NOALLOC_MAX_JOBS = 65536;
 constexpr size_t NOALLOC_FB_OFF = 0;
 constexpr size_t NOALLOC_ITEMS_OFF = NOALLOC_FB_OFF + sizeof(FullBest) * NOALLOC_MAX_JOBS;
 constexpr size_t NOALLOC_IJOBS_OFF = NOALLOC_ITEMS_OFF + sizeof(FullItem) * NOALLOC_MAX_JOBS;
-constexpr size_t NOALLOC_BYTES = NOALLOC_IJOBS_OFF + sizeof(int) * NOALLOC_MAX_JOBS;
+// ... and the device-side planner's tables (me_plan.h) for pictures of up to NOALLOC_MAX_CELLS 64x64 cells times reference
+// planes (1080p: 510 per plane): 6.1 KiB per cell.  Larger pictures are searched without bundles, job by job.
+constexpr int NOALLOC_MAX_CELLS = 1024;
+constexpr size_t NOALLOC_PLAN_OFF = (NOALLOC_IJOBS_OFF + sizeof(int) * NOALLOC_MAX_JOBS + 255) & ~(size_t)255;
+constexpr size_t NOALLOC_PLAN_BYTES = 256 * 6 + 4 * (size_t)NOALLOC_MAX_CELLS * HIER_PUS + sizeof(HierBundle) * (size_t)NOALLOC_MAX_CELLS +
+                                      4 * ((size_t)NOALLOC_MAX_CELLS + 1) + (size_t)HIER_FENC_DW * 4 * NOALLOC_MAX_CELLS +
+                                      NOALLOC_MAX_JOBS;
+constexpr size_t NOALLOC_BYTES = NOALLOC_PLAN_OFF + NOALLOC_PLAN_BYTES;
 static_assert(NOALLOC_ITEMS_OFF % 8 == 0 && NOALLOC_IJOBS_OFF % 4 == 0, "scratch carve-up alignment");
 static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 
@@ -1450,7 +1502,8 @@ int x265amd_create(int device, x265amd_ctx **out)
 #define XA_FULL_KERNELS(PIX) (const void*)k_full_items<0, PIX>, (const void*)k_full_items<1, PIX>, (const void*)k_full_items<2, PIX>, \
                              (const void*)k_full_items<3, PIX>, (const void*)k_full_items<4, PIX>, (const void*)k_full_items<6, PIX>, \
                              (const void*)k_full_items<8, PIX>, (const void*)k_full_items<12, PIX>, (const void*)k_full_items<16, PIX>
-    const void *full_kernels[] = { XA_FULL_KERNELS(uint8_t), XA_FULL_KERNELS(uint16_t), (const void*)k_full_hier };
+    const void *full_kernels[] = { XA_FULL_KERNELS(uint8_t), XA_FULL_KERNELS(uint16_t), (const void*)k_full_hier<false>,
+                                   (const void*)k_full_hier<true> };
 #undef XA_FULL_KERNELS
     e = hipSuccess;
     for (const void *k : full_kernels)
@@ -1504,7 +1557,7 @@ void x265amd_destroy(x265amd_ctx *c)
         joblist_free(c, c->batch_list);
         c->batch_list = nullptr;
     }
-    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs,
+    DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs, &c->plan_mem,
                        &c->look_pairs, &c->look_results, &c->look_progress, &c->field_results, &c->field_mvp };
     for (DevBuf *b : bufs)
         if (b->p)
@@ -2459,8 +2512,16 @@ int x265amd_me_search_batch_device(x265amd_ctx *c, int enc_plane, const int *ref
     if (int rc = ensure(c, c->fullbest, (size_t)n * sizeof(FullBest))) return rc;
     if (int rc = ensure(c, c->items, (size_t)n * sizeof(FullItem))) return rc;
     if (int rc = ensure(c, c->item_jobs, (size_t)n * sizeof(int))) return rc;
-    return launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
-                                   (FullBest*)c->fullbest.p, (FullItem*)c->items.p, (int*)c->item_jobs.p);
+    const PlaneDesc &e = c->h_planes[enc_plane];
+    const int cells_x = (e.width + 63) / 64, cells_y = (e.height + 63) / 64;
+    unsigned char *plan_mem = nullptr;
+    if (e.bpp == 1 && c->hier_ok && (int64_t)cells_x * cells_y * n_refs <= (1 << 20))
+    {
+        if (int rc = ensure(c, c->plan_mem, plan_bytes(cells_x * cells_y * n_refs, n))) return rc;
+        plan_mem = (unsigned char*)c->plan_mem.p;
+    }
+    return launch_search_unplanned(c, P, e.bpp, d_jobs, n, d_out,
+                                   (FullBest*)c->fullbest.p, (FullItem*)c->items.p, (int*)c->item_jobs.p, plan_mem, cells_x, cells_y);
 }
 
 int x265amd_me_search_batch_device_noalloc(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n_refs,
@@ -2488,9 +2549,12 @@ int x265amd_me_search_batch_device_noalloc(x265amd_ctx *c, int enc_plane, const 
         return fail(c, X265AMD_ERR_HIP, "the scratch array's device address is unknown");
     HIPCHK(c, hipStreamWaitEvent(c->stream, g_scratch_ev[c->device], 0));
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
-    const int rc = launch_search_unplanned(c, P, c->h_planes[enc_plane].bpp, d_jobs, n, d_out,
+    const PlaneDesc &e = c->h_planes[enc_plane];
+    const int cells_x = (e.width + 63) / 64, cells_y = (e.height + 63) / 64;
+    const bool plan = (int64_t)cells_x * cells_y * n_refs <= NOALLOC_MAX_CELLS && plan_bytes(cells_x * cells_y * n_refs, n) <= NOALLOC_PLAN_BYTES;
+    const int rc = launch_search_unplanned(c, P, e.bpp, d_jobs, n, d_out,
                                            (FullBest*)(sp + NOALLOC_FB_OFF), (FullItem*)(sp + NOALLOC_ITEMS_OFF),
-                                           (int*)(sp + NOALLOC_IJOBS_OFF));
+                                           (int*)(sp + NOALLOC_IJOBS_OFF), plan ? sp + NOALLOC_PLAN_OFF : nullptr, cells_x, cells_y);
     HIPCHK(c, hipEventRecord(g_scratch_ev[c->device], c->stream));
     return rc;
 }
