@@ -247,7 +247,11 @@ int x265amd_me_search_batch(x265amd_ctx *ctx, int enc_plane, const int *ref_plan
                             const x265amd_me_job *jobs, int n, x265amd_me_result *out);
 
 /* jobs / out already in device memory; asynchronous on the context's stream.
- * The caller guarantees the buffers stay valid until x265amd_sync(). */
+ * The caller guarantees the buffers stay valid until x265amd_sync().
+ * The host never sees these jobs, so the work a job list plans on the host is done by small kernels here: the
+ * FULL-search SAD jobs on the squares of each 64x64 cell's quadtree (8-bit planes) are bundled on the device and share
+ * one pass over the cell's window, as in a planned list (a 1080p FULL +-64 frame takes about 1.15 x the planned list's
+ * time); every other exhaustive job is scanned on its own. */
 int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *ref_planes, int n_refs,
                                    const x265amd_me_job *d_jobs, int n, x265amd_me_result *d_out);
 
@@ -255,7 +259,9 @@ int x265amd_me_search_batch_device(x265amd_ctx *ctx, int enc_plane, const int *r
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Identical results to x265amd_me_search_batch_device; the per-job scratch of the exhaustive kernel
  * (partial winners, work items) lives in a fixed device array inside the library instead of buffers
- * grown on demand, so: n <= 65536 jobs per call (X265AMD_ERR_INVALID beyond; split the batch); the call
+ * grown on demand (9.5 MiB per GPU; it holds the device-side planner's tables for pictures of up to 1024 64x64 cells
+ * times reference planes - 1080p with two references - and larger pictures are searched without bundles), so:
+ * n <= 65536 jobs per call (X265AMD_ERR_INVALID beyond; split the batch); the call
  * performs no hipMalloc / hipFree; all contexts on one GPU share that GPU's array: the library orders
  * every such call behind the previous one on that GPU with a stream event (created at x265amd_create),
  * so calls from several contexts or threads are serialised on the GPU rather than racing. */
