@@ -122,8 +122,6 @@ struct x265amd_ctx
     // side on auxiliary streams, so that one launch's tail overlaps the others: fork() makes the
     // auxiliary streams wait for the main one, join() the reverse.
     static constexpr int N_AUX = 3;
-    int n_cus = 256;                       // compute units of the device
-    int max_chunks = 4;                    // most chunks of a planned list (X265AMD_CHUNKS; 1: one pass, then the search kernels)
     int n_lanes = 2;                       // streams in use: 1 .. N_AUX + 1 (X265AMD_LANES); two give the overlap, more only cost hardware queues
     hipStream_t aux[N_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = { nullptr, nullptr, nullptr };
@@ -166,13 +164,6 @@ struct x265amd_joblist
     int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., quad-per-job class ..., row-per-job class ...]
     struct Launch { int first, count, lds_bytes, w4; };
     std::vector<Launch> launches;          // one k_full_items launch per LDS size class
-    // A list whose exhaustive work is all in the shared-window SAD pass runs in chunks of whole bundles: chunk k's search
-    // kernels (predictors, slab combine, sub-pel stages) run on a side stream beside chunk k + 1's pass.  Every chunk but
-    // the last is a whole number of rounds of resident workgroups, so only the last one has a partly filled round, and that
-    // one shares the GPU with the search kernels of the chunk before it.  idx_chunked = [chunk][class] job indices.
-    struct Chunk { int item0, n_items, idx0; int cls_count[JOB_CLASSES]; hipEvent_t done; };
-    std::vector<Chunk> chunks;             // empty: one pass, then the search kernels
-    DevBuf  idx_chunked;
 };
 
 namespace {
@@ -375,23 +366,21 @@ int join_streams(x265amd_ctx *c, int lanes)
 // (LR: some reference of the batch is a half-resolution set)
 template <typename PIX, bool LR>
 void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *d_jobs, const int *const *idx, const int *cnt,
-                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool side_by_side, hipStream_t only = nullptr)
+                    const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool side_by_side)
 {
-    // (only: every launch on that stream, in the order below)
-    auto lane_of = [&](int k) { return only ? only : c->lane(k); };
     // The large PUs first: they are the long-running workgroups.  A large PU's job is a dependent chain whose worker
     // wavefronts mostly wait; beside launches of small PUs (throughput-bound: they want the registers and wavefront slots)
     // it runs on four wavefronts, alone on the GPU on eight (10 % shorter chain).
     int k = 0;
-    const bool shared = (side_by_side || only) && cnt[0] + cnt[1] >= cnt[2];
+    const bool shared = side_by_side && cnt[0] + cnt[1] >= cnt[2];
     if (cnt[2] > 0 && shared)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 1024, LR, !LR>>), dim3(cnt[2]), dim3(256), 0, lane_of(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 4, 1024, LR, !LR>>), dim3(cnt[2]), dim3(256), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     else if (cnt[2] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR, !LR>>), dim3(cnt[2]), dim3(512), 0, lane_of(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 8, 1024, LR, !LR>>), dim3(cnt[2]), dim3(512), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[2], cnt[2], 2, fb, fb_stride, d_out, c->d_evals);
     if (cnt[1] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, lane_of(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 256, LR, !LR>>), dim3(cnt[1]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[1], cnt[1], 1, fb, fb_stride, d_out, c->d_evals);
     if (cnt[0] > 0)
-        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[0]), dim3(64), 0, lane_of(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
+        hipLaunchKernelGGL((k_search<JobLds<PIX, 1, 64, LR, !LR>>), dim3(cnt[0]), dim3(64), 0, c->lane(side_by_side ? k++ : 0), P, d_jobs, idx[0], cnt[0], 0, fb, fb_stride, d_out, c->d_evals);
     // the smallest PUs (one job per quad of lanes) and the leftovers of exhaustive scans (one job per 16-lane row) against
     // full-resolution references; else the general kernel, every launch taking the jobs of its own class
     for (int gc = LANE_CLASS; gc <= ROW_CLASS; gc++)
@@ -399,7 +388,7 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
         const int m = cnt[gc];
         if (m <= 0)
             continue;
-        hipStream_t st = lane_of(side_by_side ? k++ : 0);
+        hipStream_t st = c->lane(side_by_side ? k++ : 0);
         if (P.lane_on && gc == LANE_CLASS)
             hipLaunchKernelGGL((k_lane<PIX, 4>), dim3((m + 15) / 16), dim3(64), 0, st, P, d_jobs, idx[gc], m, fb, fb_stride, d_out, c->d_evals);
         else if (P.lane_on)
@@ -416,10 +405,8 @@ void launch_classes(x265amd_ctx *c, const BatchParams &P, const x265amd_me_job *
 
 int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd_me_job *d_jobs, int n,
                    const int *idx_base, const int *cls_count,
-                   const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool timing_events = true, hipStream_t only = nullptr)
+                   const FullBest *fb, int fb_stride, x265amd_me_result *d_out, bool timing_events = true)
 {
-    if (only)
-        timing_events = false;
     if (c->timing && timing_events)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const int *idx[JOB_CLASSES] = { nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -438,8 +425,8 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
     // with index lists every launch has work: run the classes side by side
     // (without them every launch visits all jobs and most workgroups leave at once: side by side as well, so that the
     // few long ones of the large-PU class do not hold up the rest)
-    const int lanes = only ? 1 : idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0) + (cnt[4] > 0))
-                                          : (n >= 4096 ? c->n_lanes : 1);
+    const int lanes = idx_base ? std::min(c->n_lanes, (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0) + (cnt[4] > 0))
+                               : (n >= 4096 ? c->n_lanes : 1);
     if (lanes > 1)
         if (int rc = fork_streams(c, lanes)) return rc;
     bool lr = false;
@@ -447,13 +434,13 @@ int launch_general(x265amd_ctx *c, const BatchParams &P0, int bpp, const x265amd
         lr = lr || c->h_planes[P.ref_planes[i]].lr_step != 0;
     P.lane_on = (!lr && !(c->flags & 128)) ? c->lane_full_area : 0;       // (tuning aid: X265AMD_FLAGS bit 7 keeps every PU in the general kernel)
     if (bpp == 1 && !lr)
-        launch_classes<uint8_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1, only);
+        launch_classes<uint8_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else if (bpp == 1)
-        launch_classes<uint8_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1, only);
+        launch_classes<uint8_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else if (!lr)
-        launch_classes<uint16_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1, only);
+        launch_classes<uint16_t, false>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     else
-        launch_classes<uint16_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1, only);
+        launch_classes<uint16_t, true>(c, P, d_jobs, idx, cnt, fb, fb_stride, d_out, lanes > 1);
     if (lanes > 1)
         if (int rc = join_streams(c, lanes)) return rc;
     HIPCHK(c, hipGetLastError());
@@ -1068,7 +1055,6 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     std::vector<HierBundle> dbundles;
     std::vector<HierItem> ditems;
     std::vector<HierQuads> dquads;
-    std::vector<int> hier_chunk_end, hier_chunk_bundle_end;
     L->n_had_bundles = L->n_had_items = L->had_lds_bytes = 0;
     const std::vector<char> in_hier = in_bundle;
     if (c->hier_ok && !(c->flags & 32)) // (tuning aid: X265AMD_FLAGS bit 5 switches the candidate-per-lane kernel off)
@@ -1110,43 +1096,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
     }
     if (!hitems.empty())
     {
-        // Chunks (see x265amd_joblist::Chunk): possible when the shared-window pass is the list's only exhaustive kernel.
-        // A round = the workgroups resident at once: per CU 160 KiB / LDS bytes of them, at most 16 wavefronts (the
-        // kernel's registers allow four per SIMD).  Items are in bundle order here, so a chunk is a range of them.
-        std::vector<int> chunk_end;         // item index behind each chunk
-        if (c->max_chunks > 1 && c->n_lanes > 1 && ditems.empty())
-        {
-            const int per_cu = std::max(1, std::min(16 / HIER_WAVES, (160 * 1024) / std::max(1, L->hier_lds_bytes)));
-            const double rounds = (double)hitems.size() / ((double)per_cu * c->n_cus);
-            const int nch = std::min(c->max_chunks, (int)std::ceil(rounds - 0.02));
-            if (nch > 1)
-            {
-                const int whole = std::max(1, (int)(rounds / nch + 0.02));       // rounds per chunk but the last
-                for (int k = 1; k < nch; k++)
-                {
-                    size_t e = std::min(hitems.size(), (size_t)k * whole * per_cu * c->n_cus);
-                    while (e > 0 && e < hitems.size() && hitems[e].bundle == hitems[e - 1].bundle)
-                        e--;                // (whole bundles: never more than a round)
-                    if (e > (chunk_end.empty() ? 0 : (size_t)chunk_end.back()) && e < hitems.size())
-                        chunk_end.push_back((int)e);
-                }
-                if (!chunk_end.empty())
-                    chunk_end.push_back((int)hitems.size());
-            }
-        }
-        hier_chunk_end = chunk_end;
-        for (size_t k = 0; k < chunk_end.size(); k++)
-            hier_chunk_bundle_end.push_back(k + 1 < chunk_end.size() ? hitems[chunk_end[k]].bundle : (int)hbundles.size());
         // picture order, dealt to the XCDs in contiguous bands (bundles were made in (row, column) order)
-        if (chunk_end.empty())
-            xcd_interleave(hitems);
-        else
-            for (size_t k = 0, a = 0; k < chunk_end.size(); a = chunk_end[k++])
-            {
-                std::vector<HierItem> seg(hitems.begin() + a, hitems.begin() + chunk_end[k]);
-                xcd_interleave(seg);
-                std::copy(seg.begin(), seg.end(), hitems.begin() + a);
-            }
+        xcd_interleave(hitems);
         L->n_hier_bundles = (int)hbundles.size();
         L->n_hier_items = (int)hitems.size();
         if (int rc = ensure(c, L->hier_bundles, hbundles.size() * sizeof(HierBundle))) return rc;
@@ -1257,47 +1208,6 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
         HIPCHK(c, hipMemcpyAsync(L->fb.p, fb.data(), fb.size() * sizeof(FullBest), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // fb dies here
     }
-    // launch order of a list that runs in chunks: [chunk][class], every segment in the order of the class's list above
-    for (x265amd_joblist::Chunk &ch : L->chunks)
-        if (ch.done)
-            hipEventDestroy(ch.done);
-    L->chunks.clear();
-    if (!hier_chunk_end.empty() && planned.empty())
-    {
-        const int nch = (int)hier_chunk_end.size();
-        std::vector<int> chunk_of(n, nch - 1);          // (a job outside the bundles: with the last chunk)
-        for (size_t b = 0, k = 0; b < hbundles.size(); b++)
-        {
-            while ((int)b >= hier_chunk_bundle_end[k])
-                k++;
-            for (int q = 0; q < HIER_PUS; q++)
-                if (hbundles[b].job[q] >= 0)
-                    chunk_of[hbundles[b].job[q]] = (int)k;
-        }
-        std::vector<int> chunked;
-        chunked.reserve(n);
-        for (int k = 0; k < nch; k++)
-        {
-            x265amd_joblist::Chunk ch;
-            ch.item0 = k ? hier_chunk_end[k - 1] : 0;
-            ch.n_items = hier_chunk_end[k] - ch.item0;
-            ch.idx0 = (int)chunked.size();
-            ch.done = nullptr;
-            for (int cls = 0, off = 0; cls < JOB_CLASSES; off += L->cls_count[cls++])
-            {
-                const size_t before = chunked.size();
-                for (int i = 0; i < L->cls_count[cls]; i++)
-                    if (chunk_of[L->order[off + i]] == k)
-                        chunked.push_back(L->order[off + i]);
-                ch.cls_count[cls] = (int)(chunked.size() - before);
-            }
-            HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
-            L->chunks.push_back(ch);
-        }
-        if (int rc = ensure(c, L->idx_chunked, (size_t)n * sizeof(int))) return rc;
-        HIPCHK(c, hipMemcpyAsync(L->idx_chunked.p, chunked.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // chunked dies here
-    }
     if (!planned.empty())
     {
         // class = smallest LDS size that holds the item; launches ordered largest class first
@@ -1350,10 +1260,7 @@ void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
         hipStreamSynchronize(c->out_stream);
     if (L->ev_ran) hipEventDestroy(L->ev_ran);
     if (L->ev_out) hipEventDestroy(L->ev_out);
-    for (x265amd_joblist::Chunk &ch : L->chunks)
-        if (ch.done)
-            hipEventDestroy(ch.done);
-    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->idx_chunked, &L->hist,
+    DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
                        &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->had_quads,
                        &L->fb_jobs };
     for (DevBuf *b : bufs)
@@ -1458,53 +1365,6 @@ int joblist_launch_search(x265amd_ctx *c, x265amd_joblist *L, const BatchParams 
                           (x265amd_me_result*)L->results.p, timing_events);
 }
 
-// A list in chunks (x265amd_joblist::Chunk): the shared-window pass chunk by chunk on the main stream, the search kernels of
-// every chunk but the last on the first side stream as soon as their chunk's pass is done, the last chunk's over all lanes.
-// The timed brackets: first = start .. end of the last chunk's pass (search kernels of earlier chunks run inside it),
-// second = from there to the end of the batch.
-int joblist_launch_chunked(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P0)
-{
-    hipStream_t st = c->stream, side = c->aux[0];
-    hipLaunchKernelGGL(k_pack_fenc, dim3(L->n_hier_bundles), dim3(256), 0, st, P0, (const HierBundle*)L->hier_bundles.p,
-                       L->n_hier_bundles, (uint32_t*)L->hier_fenc.p);
-    BatchParams P = P0;
-    P.hist = L->keep_hist ? (unsigned*)L->hist.p : nullptr;
-    P.fb_jobs = nullptr;
-    L->ran = true;
-    const size_t nch = L->chunks.size();
-    for (size_t k = 0; k < nch; k++)
-    {
-        const x265amd_joblist::Chunk &ch = L->chunks[k];
-        hipLaunchKernelGGL(k_full_hier<false>, dim3(ch.n_items), dim3(HIER_THREADS), L->hier_lds_bytes, st, P0,
-                           (const x265amd_me_job*)L->jobs.p, (const HierBundle*)L->hier_bundles.p,
-                           (const HierItem*)L->hier_items.p + ch.item0, ch.n_items, (const uint32_t*)L->hier_fenc.p,
-                           (FullBest*)L->fb.p, FB_STRIDE_PLAN);
-        HIPCHK(c, hipGetLastError());
-        if (k + 1 == nch)
-            break;
-        HIPCHK(c, hipEventRecord(ch.done, st));
-        HIPCHK(c, hipStreamWaitEvent(side, ch.done, 0));
-        if (int rc = launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n, (const int*)L->idx_chunked.p + ch.idx0, ch.cls_count,
-                                    (const FullBest*)L->fb.p, FB_STRIDE_PLAN, (x265amd_me_result*)L->results.p, false, side))
-            return rc;
-    }
-    c->timed_full = true;
-    if (c->timing)
-        HIPCHK(c, hipEventRecord(c->ev[1], st));
-    const x265amd_joblist::Chunk &last = L->chunks[nch - 1];
-    if (int rc = launch_general(c, P, L->bpp, (const x265amd_me_job*)L->jobs.p, L->n, (const int*)L->idx_chunked.p + last.idx0, last.cls_count,
-                                (const FullBest*)L->fb.p, FB_STRIDE_PLAN, (x265amd_me_result*)L->results.p, false))
-        return rc;
-    HIPCHK(c, hipEventRecord(c->ev_join[0], side));
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[0], 0));
-    if (c->timing)
-    {
-        HIPCHK(c, hipEventRecord(c->ev[2], st));
-        c->timed_any = true;
-    }
-    return 0;
-}
-
 int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
 {
     if (L->out_pending)
@@ -1513,8 +1373,6 @@ int joblist_launch(x265amd_ctx *c, x265amd_joblist *L, const BatchParams &P)
         L->out_pending = false;
     }
     if (int rc = record_start(c)) return rc;
-    if (!L->chunks.empty() && c->n_lanes > 1 && !(c->flags & 512))       // (tuning aid: X265AMD_FLAGS bit 9 runs a list in one piece)
-        return joblist_launch_chunked(c, L, P);
     if (int rc = joblist_launch_full(c, L, P)) return rc;
     c->timed_full = L->has_fb;
     return joblist_launch_search(c, L, P, true);
@@ -1657,13 +1515,6 @@ int x265amd_create(int device, x265amd_ctx **out)
         delete c;
         return X265AMD_ERR_NO_DEVICE;
     }
-    {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0)
-            c->n_cus = v;
-    }
-    if (const char *ev = getenv("X265AMD_CHUNKS"))
-        c->max_chunks = std::max(1, std::min(16, atoi(ev)));
     if (const char *ev = getenv("X265AMD_FLAGS"))        // tuning aid, see BatchParams::flags
     {
         c->flags = atoi(ev);
@@ -2810,12 +2661,6 @@ int order_by_length(x265amd_ctx *c, x265amd_joblist *L, const std::vector<unsign
         off += cnt;
     }
     HIPCHK(c, hipMemcpy(L->idx.p, L->order.data(), (size_t)L->n * sizeof(int), hipMemcpyHostToDevice));
-    // (a list that ran in chunks runs in one piece from now on: the chunks' segments would not follow the new order)
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (x265amd_joblist::Chunk &ch : L->chunks)
-        if (ch.done)
-            hipEventDestroy(ch.done);
-    L->chunks.clear();
     return 0;
 }
 } // namespace
