@@ -281,6 +281,20 @@ int x265amd_joblist_create(x265amd_ctx *ctx, const x265amd_me_job *jobs, int n, 
  * X265AMD_ERR_RANGE as for x265amd_me_search_batch */
 int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
                         x265amd_me_result *out);
+/* Two frames in flight.  x265amd_joblist_run(out = NULL) on stream set `set` of the context: 0 = the set every other
+ * call uses, 1 = a second set on hardware queues of its own.  A run queued on set 1 executes beside the work queued on
+ * set 0, so the workgroups of one frame's search fill the compute units that the end of the other frame's kernels leaves
+ * idle (1080p exhaustive frame: 0.515 -> 0.45 ms per frame with lists alternating between the sets).  Each frame needs
+ * its own list (a list's next run, on either set, starts behind its last one).  x265amd_sync waits for both sets;
+ * x265amd_joblist_results / _results_async / _eval_counts wait for the list's last run wherever it ran; a pointer from
+ * x265amd_joblist_results_device is valid after x265amd_sync.  Planes named by the call must be complete: a refill
+ * queued with x265amd_plane_refill_async is waited for, any other write to a plane (x265amd_plane_update_rows, a caller's
+ * own kernels on a wrapped plane) is ordered by the caller (x265amd_sync, or events) - work queued on set 0 is NOT awaited
+ * by a run on set 1.  The reference runs the motion searches of several frames side by side on its frame threads
+ * (encoder/encoder.cpp:199-203 `frameNumThreads`, encoder/frameencoder.cpp:285-300 FrameEncoder::threadMain ->
+ * compressFrame: one thread per frame in flight, each reaching TEncSearch::predInterSearch). */
+int x265amd_joblist_run_overlapped(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
+                                   int set);
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *list);
 /* wait for the list's last run and copy its results (list length entries) to `out` in host memory */
 int x265amd_joblist_results(x265amd_ctx *ctx, x265amd_joblist *list, x265amd_me_result *out);

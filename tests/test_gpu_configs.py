@@ -86,6 +86,42 @@ def test_bench_job_list_sampled_against_the_oracle(eng, oracle):
         eng.release_plane(i)
 
 
+def test_two_frames_in_flight_equal_one_at_a_time(eng, oracle):
+    """x265amd_joblist_run_overlapped: the headline's job list for two different current frames, one list per frame,
+    queued alternately on the engine's two stream sets (six runs back to back, no host wait between them).  Both
+    fields equal the fields of the same lists run one at a time, and a sample of each equals the oracle."""
+    import bench
+    _, full_jobs = bench.build_job_lists()
+    base = synth.base_frame(bench.W, bench.H)
+    ref = synth.pad_plane(base)
+    encs = [synth.pad_plane(synth.moved_frame(base, k)) for k in (1, 2)]
+    rid = eng.upload_plane(ref)
+    eids = [eng.upload_plane(e) for e in encs]
+    lists = [eng.make_joblist(full_jobs) for _ in range(2)]
+    alone = [lists[k].run(eids[k], [rid]) for k in range(2)]
+    assert (alone[0] != alone[1]).any()
+    eng.sync()
+    for rep in range(3):
+        for k in range(2):
+            lists[k].run_overlapped(eids[k], [rid], k)
+    got = [lists[k].results() for k in range(2)]
+    # ... and with the sets exchanged (a list's next run waits for its last one on the other set)
+    for k in range(2):
+        lists[k].run_overlapped(eids[k], [rid], 1 - k)
+    eng.sync()
+    got2 = [lists[k].results() for k in range(2)]
+    for k in range(2):
+        assert (got[k] == alone[k]).all() and (got2[k] == alone[k]).all()
+    sel = np.arange(0, len(full_jobs), 173)
+    for k in range(2):
+        exp, _ = oracle.search(encs[k], [ref], np.ascontiguousarray(full_jobs[sel]), threads=8)
+        assert (got[k][sel] == exp).all()
+    for jl in lists:
+        jl.close()
+    for i in eids + [rid]:
+        eng.release_plane(i)
+
+
 # the PU shapes of one 64x64 CTU: 2Nx2N, 2NxN, Nx2N at depths 0-3, AMP at depths 0-2, 8x4 / 4x8 at depth 3
 HEVC_PU_SHAPES = [(64, 64), (64, 32), (32, 64), (64, 16), (64, 48), (16, 64), (48, 64),
                   (32, 32), (32, 16), (16, 32), (32, 8), (32, 24), (8, 32), (24, 32),

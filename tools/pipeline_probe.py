@@ -18,7 +18,18 @@ if leg == "full":
 else:
     jobs = J.frame_jobs(W, H, sizes=(64, 16), method=J.HEX, subme=5, merange=64, qp=32)
 for depth in (1, 2, 3):
-    engs = [Engine(0) for _ in range(depth)]
+    engs = []
+    dummies = []
+    for _ in range(depth):
+        engs.append(Engine(0))
+        # (streams map to the process's hardware queues in creation order: X265AMD_PROBE_SHIFT dummy streams between two
+        # engines shift the second engine's streams onto other queues than the first one's)
+        for _ in range(int(os.environ.get("X265AMD_PROBE_SHIFT", "0"))):
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            st = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0      # (torch's streams come from a pool made at once)
+            dummies.append(st)
     ctx = []
     for e in engs:
         eid = e.wrap_device_plane(et.data_ptr(), W, H, ref.shape[1], 1, 8)

@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     L.x265amd_me_search_batch_device_noalloc.argtypes = [vp, ci, cip, ci, vp, ci, vp]
     L.x265amd_joblist_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(vp)]
     L.x265amd_joblist_run.argtypes = [vp, vp, ci, cip, ci, vp]
+    L.x265amd_joblist_run_overlapped.argtypes = [vp, vp, ci, cip, ci, ci]
     L.x265amd_joblist_results_device.argtypes = [vp]
     L.x265amd_joblist_results_device.restype = vp
     L.x265amd_joblist_results.argtypes = [vp, vp, vp]
@@ -420,6 +421,11 @@ class JobList:
         self.eng._chk(self.eng.lib.x265amd_joblist_run(self.eng.h, self.h, enc_plane, refs, len(ref_planes),
                                                        out.ctypes.data if fetch else None))
         return out
+
+    def run_overlapped(self, enc_plane: int, ref_planes, stream_set: int):
+        """asynchronous run on stream set 0 or 1 of the engine: lists alternating between the sets keep two frames in flight"""
+        refs = (C.c_int * len(ref_planes))(*ref_planes)
+        self.eng._chk(self.eng.lib.x265amd_joblist_run_overlapped(self.eng.h, self.h, enc_plane, refs, len(ref_planes), stream_set))
 
     def results(self) -> np.ndarray:
         """the results of the list's last run (waits for it): for runs queued with fetch=False"""

@@ -30,9 +30,20 @@
 
 namespace xa {
 
-constexpr int HIER_R = 4;                 // candidate rows per lane task
-constexpr int HIER_THREADS = 128;
+#ifdef XA_PROFILE
+static __device__ unsigned long long g_hier_prof[8];
+static __device__ unsigned long long g_hier_trace[3 * 16384];   // per work item of a launch: start, staged, end (100 MHz counter)     // developer aid: clocks {item total, staging, cell loop, epilogue}, items
+#endif
+#ifndef XA_HIER_R
+#define XA_HIER_R 4
+#endif
+#ifndef XA_HIER_THREADS
+#define XA_HIER_THREADS 128
+#endif
+constexpr int HIER_R = XA_HIER_R;                 // candidate rows per lane task
+constexpr int HIER_THREADS = XA_HIER_THREADS;
 constexpr int HIER_WAVES = HIER_THREADS / 64;
+constexpr int HIER_SLOT_ROWS = 4;         // winner slots of a small PU per wavefront: one per 16-lane row
 constexpr int HIER_PUS = 85;              // 64 + 16 + 4 + 1 squares of the quadtree
 constexpr int HIER_SMALL = 80;            // PUs 0..79 (8x8, 16x16) use 32-bit keys
 constexpr int HIER_RIDX_BITS = 15;        // raster index bits: window candidates <= 2^15
@@ -146,12 +157,25 @@ __device__ __forceinline__ uint32_t hier_wave_min_last(uint32_t v)
     v = hier_min_dpp<0x143, 0xc>(v);      // row_bcast31 into rows 2 and 3
     return v;
 }
-
-// what a lane knows about its task's 4 x HIER_R candidates
-struct HierCand
+// minimum over every 16-lane row of the wavefront, in all lanes of the row
+__device__ __forceinline__ uint32_t hier_row_min(uint32_t v)
 {
-    uint32_t mvr[HIER_R][4];    // (mvcost << 15) + raster index; HIER_KEY_NONE: not a candidate
-};
+    v = hier_min_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v = hier_min_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v = hier_min_dpp<0x141>(v);           // row_half_mirror
+    v = hier_min_dpp<0x140>(v);           // row_mirror
+    return v;
+}
+
+// LDS bytes of a work item besides its window and MV-cost tables: 32-bit winner slots [wavefront][16-lane row][80],
+// 64-bit slots [wavefront][5], padding of the carve-up
+__device__ __host__ constexpr int hier_slot_bytes()
+{
+    return 4 * HIER_WAVES * HIER_SLOT_ROWS * HIER_SMALL + 8 * HIER_WAVES * 5 + 64;
+}
+// LDS row pitch (dwords) of a window of nd dwords per row.  (Measured on the MI355X: the pitch makes no difference to the
+// kernel's time - its LDS reads are far from the LDS's rate - so the smallest one is taken, odd so that rows shift banks.)
+__device__ __host__ constexpr int hier_pitch(int nd) { return nd | 1; }
 
 // D = S0.u16 (low / high half) * S1.u16 + S2.u32 in one instruction
 __device__ __forceinline__ uint32_t hier_mad_lo(uint32_t p, uint32_t mul, uint32_t add)
@@ -189,11 +213,13 @@ __device__ __forceinline__ uint32_t hier_add_sat(uint32_t a, uint32_t b)
     return r;
 }
 
-// The same minimum for a job with its own predictor: cxk[x] = (x cost << 15) + column tag of candidate column x,
-// cyk[i] = (y cost << 15) + raster index of the row's first candidate; either is HIER_KEY_NONE or more for a column /
-// row outside the job's range.  The row term is the same for the 4 candidates of a row, so it is added after their
-// minimum; both steps saturate, which keeps a struck-out candidate at or above HIER_KEY_NONE.
-__device__ __forceinline__ uint32_t hier_lane_min32_pred(const unsigned long long *p, const uint32_t *cxk, const uint32_t *cyk)
+// The lane's minimum key of a small PU (8x8, 16x16) from packed 16-bit sums p[i] (4 candidates of row i).  A key is
+// (cost << 15) + raster index = (SAD << 15) + column term + row term: cxk[x] = (x cost << 15) + column tag of candidate
+// column x, cyk[i] = (y cost << 15) + raster index of the row's first candidate (less the tag of column 0); either is
+// HIER_KEY_NONE or more for a column / row that is no candidate of this job.  The row term is the same for the 4
+// candidates of a row, so it is added after their minimum; both steps saturate, which keeps a struck-out candidate at or
+// above HIER_KEY_NONE (a real key stays below it: sums <= 65280, MV costs <= HIER_MVCOST_MAX).
+__device__ __forceinline__ uint32_t hier_lane_min32(const unsigned long long *p, const uint32_t *cxk, const uint32_t *cyk)
 {
     const uint32_t mul = 1u << HIER_RIDX_BITS;
     uint32_t m = ~0u;
@@ -212,89 +238,53 @@ __device__ __forceinline__ uint32_t hier_lane_min32_pred(const unsigned long lon
     return m;
 }
 
-// The lane's minimum key of one 8x8 (SMALL8: sums <= 16320, so sum << 15 plus any mvr cannot wrap) or
-// 16x16 PU (sums <= 65280: saturating add) from packed 16-bit sums p[i] (4 candidates of row i), plus
-// optional per-job kill words
-template <bool MASK, bool SMALL8>
-__device__ __forceinline__ uint32_t hier_lane_min32(const unsigned long long *p, const HierCand &c, const uint32_t *kx, const uint32_t *ky)
-{
-    uint32_t m = ~0u;
-#pragma unroll
-    for (int i = 0; i < HIER_R; i++)
-    {
-        const uint32_t lo = (uint32_t)p[i], hi = (uint32_t)(p[i] >> 32);
-        uint32_t k[4];
-        if (SMALL8)
-        {
-            const uint32_t mul = 1u << HIER_RIDX_BITS;
-            k[0] = hier_mad_lo(lo, mul, c.mvr[i][0]); k[1] = hier_mad_hi(lo, mul, c.mvr[i][1]);
-            k[2] = hier_mad_lo(hi, mul, c.mvr[i][2]); k[3] = hier_mad_hi(hi, mul, c.mvr[i][3]);
-        }
-        else
-        {
-            const uint32_t mul = 1u << HIER_RIDX_BITS;
-            k[0] = hier_mad_lo_sat(lo, mul, c.mvr[i][0]); k[1] = hier_mad_hi_sat(lo, mul, c.mvr[i][1]);
-            k[2] = hier_mad_lo_sat(hi, mul, c.mvr[i][2]); k[3] = hier_mad_hi_sat(hi, mul, c.mvr[i][3]);
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-        {
-            if (MASK)
-                k[x] |= kx[x] | ky[i];
-            m = k[x] < m ? k[x] : m;
-        }
-    }
-    return m;
-}
-
-// The lane's best candidate of a 32x32 / 64x64 PU from 32-bit sums, as a 64-bit key (cost << 32 | raster
-// index) for the cross-lane reduction.  Inside the lane the 16 candidates are compared as
-// (cost << 4 | slot), slot = 4 * row + x being their raster order.
-template <bool MASK>
-__device__ __forceinline__ unsigned long long hier_lane_min64(const uint32_t (*s)[4], const HierCand &c, int x0, int y0, int nxw,
-                                                              int jx0, int jx1, int jy0, int jy1)
+// The lane's best candidate of a 32x32 / 64x64 PU from 32-bit sums, as a 64-bit key (cost << 32 | raster index) for
+// the cross-lane reduction; column / row terms as above (only their cost fields and "at or above HIER_KEY_NONE" are
+// used).  Inside the lane the 4 x HIER_R candidates are compared as (cost << 4 | slot), slot = 4 * row + x being their
+// raster order.
+__device__ __forceinline__ unsigned long long hier_lane_min64(const uint32_t (*s)[4], const uint32_t *cxk, const uint32_t *cyk,
+                                                              int x0, int y0, int nxw)
 {
     constexpr uint32_t BIG = 0x3ffffffu;            // "not a candidate": above every real cost (< 2^21)
     uint32_t m = ~0u;
 #pragma unroll
     for (int i = 0; i < HIER_R; i++)
-    {
-        const bool oky = !MASK || (y0 + i >= jy0 && y0 + i <= jy1);
 #pragma unroll
         for (int x = 0; x < 4; x++)
         {
-            const bool ok = c.mvr[i][x] < HIER_KEY_NONE && oky && (!MASK || (x0 + x >= jx0 && x0 + x <= jx1));
-            const uint32_t mv = ok ? c.mvr[i][x] >> HIER_RIDX_BITS : BIG;
+            const uint32_t t = hier_add_sat(cxk[x], cyk[i]);
+            const uint32_t mv = t < HIER_KEY_NONE ? t >> HIER_RIDX_BITS : BIG;
             const uint32_t k = ((s[i][x] + mv) << 4) | (uint32_t)(i * 4 + x);
             m = k < m ? k : m;
         }
-    }
     const uint32_t cost = m >> 4, slot = m & 15;
     if (cost >= BIG)
         return ~0ull;
     return ((unsigned long long)cost << 32) | (uint32_t)((y0 + (int)(slot >> 2)) * nxw + x0 + (int)(slot & 3));
 }
 
-// per-job kill words of the lane's candidates (MASK bundles: a job's own range is smaller than the window)
+// One predictor for the whole bundle: the lane's column / row terms cxs / cys serve every job; a job whose own range is
+// smaller than the window (MASK) strikes out the columns / rows outside it.
 template <bool MASK>
-__device__ __forceinline__ void hier_job_mask(const x265amd_me_job *jobs, int jid, const HierBundle &B, int x0, int y0, uint32_t *kx, uint32_t *ky)
+__device__ __forceinline__ void hier_plain_terms(const x265amd_me_job *jobs, int jid, const HierBundle &B, int x0, int y0,
+                                                 const uint32_t *cxs, const uint32_t *cys, uint32_t *cxk, uint32_t *cyk)
 {
 #pragma unroll
     for (int x = 0; x < 4; x++)
-        kx[x] = 0;
+        cxk[x] = cxs[x];
 #pragma unroll
     for (int i = 0; i < HIER_R; i++)
-        ky[i] = 0;
+        cyk[i] = cys[i];
     if (MASK)
     {
         const x265amd_me_job &J = jobs[jid];
         const int jx0 = J.mvmin_x - B.mvx0, jx1 = J.mvmax_x - B.mvx0, jy0 = J.mvmin_y - B.mvy0, jy1 = J.mvmax_y - B.mvy0;
 #pragma unroll
         for (int x = 0; x < 4; x++)
-            kx[x] = (x0 + x >= jx0 && x0 + x <= jx1) ? 0u : ~0u;
+            cxk[x] = (x0 + x >= jx0 && x0 + x <= jx1) ? cxs[x] : HIER_KEY_NONE;
 #pragma unroll
         for (int i = 0; i < HIER_R; i++)
-            ky[i] = (y0 + i >= jy0 && y0 + i <= jy1) ? 0u : ~0u;
+            cyk[i] = (y0 + i >= jy0 && y0 + i <= jy1) ? cys[i] : HIER_KEY_NONE;
     }
 }
 
@@ -346,21 +336,6 @@ __device__ __forceinline__ void hier_pred_terms(const uint32_t *s_tx, const uint
     }
 }
 
-template <bool KILL>
-__device__ __forceinline__ unsigned long long hier_lane_min64_pred(const uint32_t (*s)[4], const uint32_t *s_tx, const uint32_t *s_ty, const HierPredPu &d,
-                                                                   int x0, int y0, int nxw, const uint32_t *ry)
-{
-    uint32_t cxk[4], cyk[HIER_R];
-    hier_pred_terms<KILL>(s_tx, s_ty, d, x0, y0, ry, cxk, cyk);
-    HierCand c;
-#pragma unroll
-    for (int i = 0; i < HIER_R; i++)
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-            c.mvr[i][x] = hier_add_sat(cxk[x], cyk[i]);     // (only the cost field and "at or above HIER_KEY_NONE" are used)
-    return hier_lane_min64<false>(s, c, x0, y0, nxw, 0, 0, 0, 0);
-}
-
 // MODE 0: one predictor, every job's range is the window; 1: one predictor, per-job ranges; 2: per-job predictors, every job's
 // range is the same around its predictor; 3: per-job predictors and ranges
 template <int MODE, bool KEYS>
@@ -375,7 +350,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
     const int XG = (nxw + 3) >> 2;
     const int yq_lo = it.t_lo / XG;                 // first row quad of this slab = first staged candidate row / R
 
-    // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][80] | 64-bit slots [waves][5]
+    // LDS: window | cx[nxw] cy[nyw] (u16) | 32-bit slots [waves][16-lane rows][80] | 64-bit slots [waves][5]
     // (the window area is rounded up to an even dword count, so the 64-bit slots behind it are 8-byte aligned)
     // several predictors: window (a multiple of 4 dwords) | HierPredPu[85] | the slots | phase tables x[4][lxp] y[4][lyp] (u32)
     uint32_t *s_win = lds;
@@ -386,9 +361,13 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
     const int lxp = (B.lx + 3) & ~3, lyp = (B.ly + 3) & ~3;
     if (PRED)
         s_slot = (uint32_t*)(s_pd + HIER_PUS + 1);
-    unsigned long long *s_big = (unsigned long long*)(s_slot + HIER_WAVES * HIER_SMALL);
+    unsigned long long *s_big = (unsigned long long*)(s_slot + HIER_WAVES * HIER_SLOT_ROWS * HIER_SMALL);
     uint32_t *s_tx = (uint32_t*)(s_big + HIER_WAVES * 5 + 1), *s_ty = s_tx + 4 * lxp;
 
+#ifdef XA_PROFILE
+    const long long t_begin = XA_TICK();
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- stage the window rows of this slab, the MV-cost slices, and clear the slots
     {
         const uint8_t *r0 = (const uint8_t*)ref.origin;
@@ -453,13 +432,21 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             for (int i = tid; i < nyw; i += HIER_THREADS)
                 s_cy[i] = cost[(int16_t)((int16_t)((B.mvy0 + i) << 2) - B.qmvp_y)];
         }
-        for (int i = tid; i < HIER_WAVES * HIER_SMALL; i += HIER_THREADS)
+        for (int i = tid; i < HIER_WAVES * HIER_SLOT_ROWS * HIER_SMALL; i += HIER_THREADS)
             s_slot[i] = ~0u;
         if (tid < HIER_WAVES * 5)
             s_big[tid] = ~0ull;
     }
     __syncthreads();
+#ifdef XA_PROFILE
+    const long long t_staged = XA_TICK();
+    const unsigned long long r_staged = __builtin_amdgcn_s_memrealtime();
+#endif
 
+    // which squares of the quadtree have a job, as wave-uniform masks (no look-up per cell in the loop below):
+    // has8 bit z: 8x8 cell z; hasb bits 0..15: 16x16 blocks, 16..19: 32x32 blocks, 20: the 64x64 block
+    const uint64_t has8 = __ballot(B.job[lane] >= 0);
+    const uint32_t hasb = (uint32_t)__ballot(lane < HIER_PUS - 64 && B.job[64 + (lane < HIER_PUS - 64 ? lane : 0)] >= 0);
     const uint64_t cells = B.cells;
     for (int base = it.t_lo; base < it.t_hi; base += HIER_THREADS)
     {
@@ -468,7 +455,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
         const int tk = active ? task : it.t_lo;
         const int yq = tk / XG, xg = tk - yq * XG;
         const int x0 = 4 * xg, y0 = R * yq;
-        HierCand C;
+        uint32_t cxs[4], cys[R];        // one predictor: column / row terms of the lane's candidates' keys (hier_lane_min32)
         uint32_t ry[R];                 // several predictors: raster index of the first candidate of the lane's rows
 #pragma unroll
         for (int i = 0; i < R; i++)
@@ -477,15 +464,15 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             const bool vy = active && y < nyw;
             ry[i] = vy ? (uint32_t)(y * nxw) : HIER_KEY_NONE;
             if (!PRED)
-            {
-                const uint32_t cyv = s_cy[y < nyw ? y : nyw - 1];
+                cys[i] = vy ? ((uint32_t)s_cy[y < nyw ? y : nyw - 1] << HIER_RIDX_BITS) + (uint32_t)(y * nxw) : HIER_KEY_NONE;
+        }
+        if (!PRED)
+        {
 #pragma unroll
-                for (int x = 0; x < 4; x++)
-                {
-                    const int xx = x0 + x;
-                    const uint32_t mv = (s_cx[xx < nxw ? xx : nxw - 1] + cyv) & 0xffffu;
-                    C.mvr[i][x] = (vy && xx < nxw) ? (mv << HIER_RIDX_BITS) + (uint32_t)(y * nxw + xx) : HIER_KEY_NONE;
-                }
+            for (int x = 0; x < 4; x++)
+            {
+                const int xx = x0 + x;
+                cxs[x] = (active && xx < nxw) ? ((uint32_t)s_cx[xx < nxw ? xx : nxw - 1] << HIER_RIDX_BITS) + (uint32_t)xx : HIER_KEY_NONE;
             }
         }
         const uint32_t *wbase = s_win + (R * (yq - yq_lo)) * pitch + xg;
@@ -501,8 +488,9 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 a64[i][x] = a32[i][x] = 0;
         }
 
-        // the covered cells in Z-order; the next cell's encoder pixels are fetched (scalar loads) while
-        // the current cell is measured
+        // the covered cells in Z-order; the next cell's encoder pixels (scalar loads) and window rows (LDS reads into
+        // registers) are fetched while the current cell is measured and priced, so that a wavefront on its own - the
+        // last work items of a launch - does not wait for the LDS at every cell
         uint64_t rem = cells;
         int z = rem ? __builtin_ctzll(rem) : 64;
         uint32_t f[16];
@@ -511,6 +499,18 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 f[e] = fe[e];
+        }
+        unsigned long long w[8 + R - 1][2];     // window rows of the cell: dword pairs (k, k + 1) and (k + 1, k + 2)
+        {
+            int cx, cy;
+            hier_cell_xy(z & 63, cx, cy);
+            const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
+#pragma unroll
+            for (int r = 0; r < 8 + R - 1; r++)
+            {
+                w[r][0] = lds_pair(row + r * pitch);
+                w[r][1] = lds_pair(row + r * pitch + 1);
+            }
         }
 #pragma nounroll
         while (z < 64)
@@ -524,9 +524,6 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 for (int e = 0; e < 16; e++)
                     fn[e] = fe[e];
             }
-            int cx, cy;
-            hier_cell_xy(z, cx, cy);
-            const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
             unsigned long long p[R];
 #pragma unroll
             for (int i = 0; i < R; i++)
@@ -534,40 +531,41 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 #pragma unroll
             for (int r = 0; r < 8 + R - 1; r++)
             {
-                const unsigned long long d0 = lds_pair(row + r * pitch), d1 = lds_pair(row + r * pitch + 1);
 #pragma unroll
                 for (int i = 0; i < R; i++)
                 {
                     const int e = r - i;            // encoder row that window row r meets in candidate row i
                     if (e >= 0 && e < 8)
                     {
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d0, f[2 * e], p[i]);
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d1, f[2 * e + 1], p[i]);
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[r][0], f[2 * e], p[i]);
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[r][1], f[2 * e + 1], p[i]);
                     }
                 }
             }
-            // 8x8 PU of this cell
-            const int j8 = B.job[z];
-            if (j8 >= 0)
+            asm volatile("" ::: "memory");      // (the reads below start before the pricing, not behind it)
             {
-                uint32_t m;
+                int cx, cy;
+                hier_cell_xy(nz & 63, cx, cy);
+                const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
+#pragma unroll
+                for (int r = 0; r < 8 + R - 1; r++)
+                {
+                    w[r][0] = lds_pair(row + r * pitch);
+                    w[r][1] = lds_pair(row + r * pitch + 1);
+                }
+            }
+            asm volatile("" ::: "memory");
+            // 8x8 PU of this cell
+            if ((has8 >> z) & 1)
+            {
+                uint32_t cxk[4], cyk[R];
                 if (PRED)
-                {
-                    uint32_t cxk[4], cyk[R];
                     hier_pred_terms<KILL>(s_tx, s_ty, s_pd[z], x0, y0, ry, cxk, cyk);
-                    m = hier_lane_min32_pred(p, cxk, cyk);
-                }
                 else
-                {
-                    uint32_t kx[4], ky[R];
-                    hier_job_mask<MASK>(jobs, j8, B, x0, y0, kx, ky);
-                    m = hier_lane_min32<MASK, true>(p, C, kx, ky);
-                }
-                m = hier_wave_min_last(m);
-                if (lane == 63)
-                {
-                    atomicMin(s_slot + wv * HIER_SMALL + z, m);        // (ds_min_u32: no read-back to wait for)
-                }
+                    hier_plain_terms<MASK>(jobs, MASK ? B.job[z] : 0, B, x0, y0, cxs, cys, cxk, cyk);
+                const uint32_t m = hier_row_min(hier_lane_min32(p, cxk, cyk));
+                if ((lane & 15) == 15)
+                    atomicMin(s_slot + (wv * HIER_SLOT_ROWS + (lane >> 4)) * HIER_SMALL + z, m);    // (ds_min_u32: no read-back to wait for)
             }
 #pragma unroll
             for (int i = 0; i < R; i++)
@@ -575,27 +573,16 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             if ((nz >> 2) != (z >> 2))      // the 16x16 block is complete
             {
                 const int q = z >> 2;
-                const int j16 = B.job[64 + q];
-                if (j16 >= 0)
+                if ((hasb >> q) & 1)
                 {
-                    uint32_t m;
+                    uint32_t cxk[4], cyk[R];
                     if (PRED)
-                    {
-                        uint32_t cxk[4], cyk[R];
                         hier_pred_terms<KILL>(s_tx, s_ty, s_pd[64 + q], x0, y0, ry, cxk, cyk);
-                        m = hier_lane_min32_pred(a16, cxk, cyk);
-                    }
                     else
-                    {
-                        uint32_t kx[4], ky[R];
-                        hier_job_mask<MASK>(jobs, j16, B, x0, y0, kx, ky);
-                        m = hier_lane_min32<MASK, false>(a16, C, kx, ky);
-                    }
-                    m = hier_wave_min_last(m);
-                    if (lane == 63)
-                    {
-                        atomicMin(s_slot + wv * HIER_SMALL + 64 + q, m);
-                    }
+                        hier_plain_terms<MASK>(jobs, MASK ? B.job[64 + q] : 0, B, x0, y0, cxs, cys, cxk, cyk);
+                    const uint32_t m = hier_row_min(hier_lane_min32(a16, cxk, cyk));
+                    if ((lane & 15) == 15)
+                        atomicMin(s_slot + (wv * HIER_SLOT_ROWS + (lane >> 4)) * HIER_SMALL + 64 + q, m);
                 }
 #pragma unroll
                 for (int i = 0; i < R; i++)
@@ -608,19 +595,14 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 if ((nz >> 4) != (z >> 4))  // the 32x32 block is complete
                 {
                     const int q32 = z >> 4;
-                    const int j32 = B.job[80 + q32];
-                    if (j32 >= 0)
+                    if ((hasb >> (16 + q32)) & 1)
                     {
-                        unsigned long long m;
+                        uint32_t cxk[4], cyk[R];
                         if (PRED)
-                            m = hier_lane_min64_pred<KILL>(a32, s_tx, s_ty, s_pd[80 + q32], x0, y0, nxw, ry);
+                            hier_pred_terms<KILL>(s_tx, s_ty, s_pd[80 + q32], x0, y0, ry, cxk, cyk);
                         else
-                        {
-                            const x265amd_me_job &J = jobs[j32];
-                            m = hier_lane_min64<MASK>(a32, C, x0, y0, nxw,
-                                                      J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
-                        }
-                        m = wave_min_u64(m);
+                            hier_plain_terms<MASK>(jobs, MASK ? B.job[80 + q32] : 0, B, x0, y0, cxs, cys, cxk, cyk);
+                        const unsigned long long m = wave_min_u64(hier_lane_min64(a32, cxk, cyk, x0, y0, nxw));
                         if (lane == 0)
                             atomicMin(s_big + wv * 5 + q32, m);         // (ds_min_u64)
                     }
@@ -639,23 +621,21 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 f[e] = fn[e];
             z = nz;
         }
-        const int j64 = B.job[84];
-        if (j64 >= 0)
+        if ((hasb >> 20) & 1)
         {
-            unsigned long long m;
+            uint32_t cxk[4], cyk[R];
             if (PRED)
-                m = hier_lane_min64_pred<KILL>(a64, s_tx, s_ty, s_pd[84], x0, y0, nxw, ry);
+                hier_pred_terms<KILL>(s_tx, s_ty, s_pd[84], x0, y0, ry, cxk, cyk);
             else
-            {
-                const x265amd_me_job &J = jobs[j64];
-                m = hier_lane_min64<MASK>(a64, C, x0, y0, nxw,
-                                          J.mvmin_x - B.mvx0, J.mvmax_x - B.mvx0, J.mvmin_y - B.mvy0, J.mvmax_y - B.mvy0);
-            }
-            m = wave_min_u64(m);
+                hier_plain_terms<MASK>(jobs, MASK ? B.job[84] : 0, B, x0, y0, cxs, cys, cxk, cyk);
+            const unsigned long long m = wave_min_u64(hier_lane_min64(a64, cxk, cyk, x0, y0, nxw));
             if (lane == 0)
                 atomicMin(s_big + wv * 5 + 4, m);
         }
     }
+#ifdef XA_PROFILE
+    const long long t_looped = XA_TICK();
+#endif
     __syncthreads();
 
     // ---- one thread per PU combines the wavefronts' winners and writes the slab's partial result
@@ -669,7 +649,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             if (tid < HIER_SMALL)
             {
                 uint32_t m = ~0u;
-                for (int w = 0; w < HIER_WAVES; w++)
+                for (int w = 0; w < HIER_WAVES * HIER_SLOT_ROWS; w++)
                 {
                     const uint32_t v = s_slot[w * HIER_SMALL + tid];
                     m = v < m ? v : m;
@@ -710,13 +690,30 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 fb[(size_t)jid * fb_stride + it.slot] = f;
         }
     }
+#ifdef XA_PROFILE
+    if (tid == 0)
+    {
+        const long long t_end = XA_TICK();
+        atomicAdd(&g_hier_prof[0], (unsigned long long)(t_end - t_begin));
+        atomicAdd(&g_hier_prof[1], (unsigned long long)(t_staged - t_begin));
+        atomicAdd(&g_hier_prof[2], (unsigned long long)(t_looped - t_staged));
+        atomicAdd(&g_hier_prof[3], (unsigned long long)(t_end - t_looped));
+        atomicAdd(&g_hier_prof[4], 1ull);
+        if (blockIdx.x < 16384)
+        {
+            g_hier_trace[3 * blockIdx.x] = r_begin;
+            g_hier_trace[3 * blockIdx.x + 1] = r_staged;
+            g_hier_trace[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // KEYS = false: the work items of a planned list, results in one FullBest slot per (job, slab).  KEYS = true: bundles
 // formed on the device - `items` is the offsets array described above, n_items the number of cells, a job's slabs meet in
 // one 64-bit key, and fb_stride = -(LDS size class of this launch, plan_lds_class): every class has a launch of its own.
 template <bool KEYS>
-__global__ void __launch_bounds__(HIER_THREADS) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+__global__ void __launch_bounds__(HIER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                             const HierItem *items, int n_items, const uint32_t *packed,
                                                             FullBest *fb, int fb_stride)
 {

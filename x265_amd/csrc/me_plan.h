@@ -178,22 +178,13 @@ __global__ void __launch_bounds__(64) k_plan_bundles(BatchParams P, DevPlan D, c
         return;
     // slabs of one lane task per thread (more only when that would exceed the work items of a bundle)
     const int XG = (nxw + 3) >> 2, nd = XG + 16;
-    int pitch = nd, best = 64;
-    for (int p = nd; p < nd + 32; p++)
-    {
-        const int d = ((HIER_R * p - XG) % 32 + 32) % 32, dd = imin(d, 32 - d);
-        if (dd < best)
-        {
-            best = dd;
-            pitch = p;
-        }
-    }
+    const int pitch = hier_pitch(nd);
     const int nquads = (nyw + HIER_R - 1) / HIER_R, ntasks = nquads * XG;
     int per = HIER_THREADS;
     while ((ntasks + per - 1) / per > PLAN_SLABS)
         per += HIER_THREADS;
     const int fixed = (pred ? 16 * (lxp + lyp) + 16 * (HIER_PUS + 1) + 32 : 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3))) +
-                      4 * HIER_WAVES * HIER_SMALL + 8 * HIER_WAVES * 5 + 64;
+                      hier_slot_bytes();
     int lds_need = 0;
     for (int t = 0; t < ntasks; t += per)
     {

@@ -131,12 +131,44 @@ struct x265amd_ctx
     bool        up_stream_owned = false;
     hipEvent_t  ev_mark = nullptr;
     hipEvent_t  plane_filled[MAX_PLANES] = {};
-    bool        fill_pending[MAX_PLANES] = {};
+    unsigned char fill_pending[MAX_PLANES] = {};   // bit s: stream set s has not yet waited for the plane's last refill
     // results leave on a stream of their own (x265amd_joblist_results_async), so that a download does not hold up the
     // next batch on the main stream; created on first use
     hipStream_t out_stream = nullptr;
     x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
     hipStream_t lane(int k) const { return (k % n_lanes) == 0 ? stream : aux[(k % n_lanes) - 1]; }
+    // Stream sets: set 0 = { stream, aux[0] }, set 1 = { aux[1], aux[2] }, each stream on a hardware queue of its own (the
+    // four are created back to back).  A batch queued on set 1 runs beside one queued on set 0 (x265amd_joblist_run_overlapped).
+    int cur_set = 0;
+};
+
+// For the lifetime of the object the context's main and first side stream are those of stream set `set`
+struct StreamSet
+{
+    x265amd_ctx *c;
+    int set, lanes;
+    StreamSet(x265amd_ctx *ctx, int s) : c(ctx), set(s), lanes(ctx->n_lanes)
+    {
+        if (set)
+        {
+            std::swap(c->stream, c->aux[1]);
+            std::swap(c->aux[0], c->aux[2]);
+            std::swap(c->ev_join[0], c->ev_join[2]);
+            c->n_lanes = std::min(c->n_lanes, 2);
+            c->cur_set = 1;
+        }
+    }
+    ~StreamSet()
+    {
+        if (set)
+        {
+            std::swap(c->stream, c->aux[1]);
+            std::swap(c->aux[0], c->aux[2]);
+            std::swap(c->ev_join[0], c->ev_join[2]);
+            c->n_lanes = lanes;
+            c->cur_set = 0;
+        }
+    }
 };
 
 // A planned job list: the jobs live in device memory together with the work-item plan of the
@@ -160,6 +192,8 @@ struct x265amd_joblist
     bool    ran = false;
     hipEvent_t ev_ran = nullptr, ev_out = nullptr;   // behind the last run / behind the last asynchronous download of the results
     bool    out_pending = false;          // a download may still read `results`: the next run waits for ev_out
+    hipEvent_t ev_done = nullptr;         // behind the list's last run, on the main stream of the set it ran on
+    int     last_set = -1;                // stream set of the last run (-1: none yet)
     bool    keep_hist = true;             // record per-job evaluation counts (for x265amd_joblist_rebalance)
     int     cls_count[JOB_CLASSES] = { 0, 0, 0, 0, 0 };   // idx = [class 0 ..., class 1 ..., class 2 ..., quad-per-job class ..., row-per-job class ...]
     struct Launch { int first, count, lds_bytes, w4; };
@@ -325,10 +359,10 @@ int wait_plane_fills(x265amd_ctx *c, int enc_plane, const int *ref_planes, int n
     for (int k = -1; k < n_refs; k++)
     {
         const int id = k < 0 ? enc_plane : ref_planes[k];
-        if (c->fill_pending[id])
+        if (c->fill_pending[id] & (1 << c->cur_set))
         {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->plane_filled[id], 0));
-            c->fill_pending[id] = false;
+            c->fill_pending[id] &= ~(1 << c->cur_set);
         }
     }
     return 0;
@@ -987,18 +1021,21 @@ void plan_hier(const x265amd_me_job *jobs, int n, int bpp, bool had, std::vector
                 pitch = p;
             }
         }
+        if (!had)
+            pitch = hier_pitch(nd);
         // slabs of one lane task per thread (more per thread only when that would exceed the FullBest slots)
         const int nquads = (nyw + RT - 1) / RT, ntasks = nquads * XG;
         const int threads = had ? had_threads : HIER_THREADS;
         int per = threads;
         while ((ntasks + per - 1) / per > FB_STRIDE_PLAN)
             per += threads;
+
         if (had && per * NC > (1 << HAD_RIDX_BITS))
             continue;
         const int slot_waves = had ? HAD_WAVES : HIER_WAVES;
         const int fixed = (had ? (B.uniform ? 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3)) : 8 * (lxp + lyp))
                                : B.pred ? 16 * (lxp + lyp) + 16 * (HIER_PUS + 1) + 32 : 2 * (((nxw + 3) & ~3) + ((nyw + 3) & ~3))) +
-                          4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 +
+                          (had ? 4 * slot_waves * HIER_SMALL + 8 * slot_waves * 5 + 64 : hier_slot_bytes()) +
                           (n_rect ? 8 * (threads / 64) * HIER_MAX_RECT : 0) + (B.quads ? 4 * (threads / 64) * HIER_QUAD_PUS : 0);
         bool fits = true;
         std::vector<HierItem> mine;
@@ -1256,10 +1293,12 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->aux[1]);       // (a run on the second stream set)
     if (c->out_stream)
         hipStreamSynchronize(c->out_stream);
     if (L->ev_ran) hipEventDestroy(L->ev_ran);
     if (L->ev_out) hipEventDestroy(L->ev_out);
+    if (L->ev_done) hipEventDestroy(L->ev_done);
     DevBuf *bufs[] = { &L->jobs, &L->results, &L->fb, &L->items, &L->item_jobs, &L->idx, &L->hist,
                        &L->hier_bundles, &L->hier_items, &L->hier_fenc, &L->had_bundles, &L->had_items, &L->had_fenc, &L->had_quads,
                        &L->fb_jobs };
@@ -1593,6 +1632,7 @@ int x265amd_sync(x265amd_ctx *c)
     if (!c)
         return X265AMD_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->aux[1]));               // runs on the second stream set
     if (c->out_stream)
         HIPCHK(c, hipStreamSynchronize(c->out_stream));       // asynchronous result downloads
     if (c->up_stream)
@@ -1785,7 +1825,7 @@ int x265amd_plane_refill_async(x265amd_ctx *c, int id, const void *host_base)
         HIPCHK(c, hipMemcpyAsync(c->base[id], host_base, bytes, hipMemcpyHostToDevice, c->up_stream));
     }
     HIPCHK(c, hipEventRecord(c->plane_filled[id], c->up_stream));
-    c->fill_pending[id] = true;
+    c->fill_pending[id] = 3;
     return 0;
 }
 
@@ -1805,7 +1845,7 @@ int x265amd_plane_release(x265amd_ctx *c, int id)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->up_stream)
         HIPCHK(c, hipStreamSynchronize(c->up_stream));
-    c->fill_pending[id] = false;
+    c->fill_pending[id] = 0;
     if (c->owned[id])
         hipFree(c->owned[id]);
     c->used[id] = false;
@@ -2582,13 +2622,27 @@ int x265amd_joblist_create(x265amd_ctx *c, const x265amd_me_job *jobs, int n, in
     return 0;
 }
 
-int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs,
-                        x265amd_me_result *out)
+namespace {
+// the main stream waits for the list's last run if that ran on the other stream set
+int wait_list_done(x265amd_ctx *c, x265amd_joblist *L)
 {
-    if (!c || !L)
+    if (L->last_set >= 0 && L->last_set != c->cur_set)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L->ev_done, 0));
+    return 0;
+}
+} // namespace
+
+static int joblist_run_on(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs,
+                          x265amd_me_result *out, int set)
+{
+    if (!c || !L || set < 0 || set > 1)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    StreamSet on(c, set);
+    if (!L->ev_done)
+        HIPCHK(c, hipEventCreateWithFlags(&L->ev_done, hipEventDisableTiming));
+    if (int rc = wait_list_done(c, L)) return rc;
     if (int rc = check_batch_planes(c, enc_plane, ref_planes, n_refs)) return rc;
     if (int rc = wait_plane_fills(c, enc_plane, ref_planes, n_refs)) return rc;
     if (c->h_planes[enc_plane].bpp != L->bpp)
@@ -2614,12 +2668,25 @@ int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const
     if (int rc = sync_planes(c)) return rc;
     BatchParams P = make_params(c, enc_plane, ref_planes, n_refs);
     if (int rc = joblist_launch(c, L, P)) return rc;
+    HIPCHK(c, hipEventRecord(L->ev_done, c->stream));
+    L->last_set = set;
     if (out)
     {
         HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return 0;
+}
+
+int x265amd_joblist_run(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs,
+                        x265amd_me_result *out)
+{
+    return joblist_run_on(c, L, enc_plane, ref_planes, n_refs, out, 0);
+}
+
+int x265amd_joblist_run_overlapped(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs, int set)
+{
+    return joblist_run_on(c, L, enc_plane, ref_planes, n_refs, nullptr, set);
 }
 
 const x265amd_me_result *x265amd_joblist_results_device(const x265amd_joblist *L)
@@ -2635,6 +2702,7 @@ int x265amd_joblist_results(x265amd_ctx *c, x265amd_joblist *L, x265amd_me_resul
     HIPCHK(c, hipSetDevice(c->device));
     if (!L->ran)
         return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    if (int rc = wait_list_done(c, L)) return rc;
     HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -2673,6 +2741,7 @@ int x265amd_joblist_eval_counts(x265amd_ctx *c, x265amd_joblist *L, uint32_t *ou
     HIPCHK(c, hipSetDevice(c->device));
     if (!L->ran || !L->keep_hist)
         return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    if (int rc = wait_list_done(c, L)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, L->hist.p, (size_t)L->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
@@ -2719,6 +2788,7 @@ int x265amd_joblist_results_async(x265amd_ctx *c, x265amd_joblist *L, x265amd_me
     HIPCHK(c, hipSetDevice(c->device));
     if (!L->ran)
         return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    if (int rc = wait_list_done(c, L)) return rc;
     // Page-locked, device-mapped host memory is written by a small kernel behind the run on the main stream (a few
     // microseconds; queueing a DMA copy costs the host about 0.1 ms per call on this platform, and one more stream
     // would share a hardware queue with the caller's upload stream).  Anything else: hipMemcpyAsync on a stream of
@@ -2819,6 +2889,21 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
                     fp[4], fp[0] / fp[4], fp[1] / fp[4], fp[2] / fp[4], fp[3] / fp[4], fp[7] / (double)fp[4] / 100.0,
                     fp[7] ? fp[0] / (fp[7] / 100.0) : 0.0);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_full_prof), zero, sizeof(zero)));
+        HIPCHK(c, hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_hier_prof), sizeof(fp)));
+        if (fp[4])
+            fprintf(stderr, "shared-window pass (wave 0 of %llu items), clocks per item: total %llu  staging %llu  cell loop %llu  epilogue %llu\n",
+                    fp[4], fp[0] / fp[4], fp[1] / fp[4], fp[2] / fp[4], fp[3] / fp[4]);
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_hier_prof), zero, sizeof(zero)));
+        if (const char *path = getenv("X265AMD_HIER_TRACE"))        // per work item: start, staged, end
+        {
+            std::vector<unsigned long long> tr(3 * 16384);
+            HIPCHK(c, hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_hier_trace), tr.size() * 8));
+            if (FILE *fo = fopen(path, "wb"))
+            {
+                fwrite(tr.data(), 8, tr.size(), fo);
+                fclose(fo);
+            }
+        }
     }
 #endif
     if (reset)
