@@ -145,8 +145,8 @@ def sharded_legs(eng, dev, rank, world, args, barrier, dist):
         barrier()
         t0 = time.perf_counter()
         b_us = sum(bcast(t) for t in refs) if grouped else 0.0     # once per batch
-        for f in mine:
-            jls[f].run(enc_ids[f], ref_ids, fetch=False)
+        for i, f in enumerate(mine):
+            jls[f].run_overlapped(enc_ids[f], ref_ids, i & 1)       # (a rank's frames two in flight: the references are complete here)
         eng.sync()
         barrier()
         times.append(time.perf_counter() - t0)
@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--only-primary", action="store_true",
                     help="run only the leg `value` is quoted on (for profiler runs: every launch of the search "
                          "kernels then belongs to that leg) and print a reduced line")
+    ap.add_argument("--in-flight", type=int, default=4, choices=(1, 2, 3, 4),
+                    help="frames in flight on the GPU (x265amd_joblist_run_overlapped: one job list and one stream set per frame "
+                         "in flight; the pattern-search legs use at most 2); 1 = one frame at a time")
     ap.add_argument("--primary", choices=("full", "hex"), default="full",
                     help="with --only-primary: which leg to run alone (profiling aid; `value` is always the FULL leg otherwise)")
     args = ap.parse_args()
@@ -314,6 +317,13 @@ def main():
     # planned job lists: jobs, work-item plan and result buffers live in device memory
     jl_hex = eng.make_joblist(hex_jobs)
     jl_full = eng.make_joblist(full_jobs)
+    # frames in flight: one list (jobs, plan, result buffers) and one stream set per frame.  The exhaustive frames take the
+    # single-stream sets 4 .. 7, the pattern-search frames the two two-stream sets 0 / 1 (measured: the best of each kind)
+    depth_full = max(1, args.in_flight)
+    depth_hex = min(2, depth_full)
+    full_lists = [jl_full] + [eng.make_joblist(full_jobs) for _ in range(depth_full - 1)]
+    hex_lists = [jl_hex] + [eng.make_joblist(hex_jobs) for _ in range(depth_hex - 1)]
+    FULL_SETS, HEX_SETS = (4, 5, 6, 7)[:depth_full], (0, 1)[:depth_hex]
     eng.set_timing(True)
     trace("job lists planned")
     from x265_amd import dist as xd
@@ -335,15 +345,20 @@ def main():
     step_no = [0]
     host_queue = [0.0]
 
-    def step(jl):
-        # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame; no host waits
+    def step(lists, sets):
+        # reference plane: rank 0 -> all (RCCL over xGMI when N > 1), then this rank's frame; no host waits.  Frames in
+        # flight: step k takes list k mod depth on that list's stream set, so consecutive frames run side by side
         k = step_no[0]
         step_no[0] += 1
-        b = ring.acquire(k)
+        i = k % len(lists)
+        b = ring.acquire(k, sets[i] if len(lists) > 1 else 0)
         trace("step %d: reference in buffer %d" % (k, b))
-        jl.run(enc_id, [ref_ids[b]], fetch=False)
+        if len(lists) > 1:
+            lists[i].run_overlapped(enc_id, [ref_ids[b]], sets[i])
+        else:
+            lists[0].run(enc_id, [ref_ids[b]], fetch=False)
         ring.prefetch(k + 1)
-        ring.release(k)
+        ring.release(k, sets[i] if len(lists) > 1 else 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -351,30 +366,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(jl, warmup, steps):
-        """K steps queued back to back (no host wait inside the timed region); kernel times of the last step."""
-        for _ in range(warmup):
-            step(jl)
+    def timed(lists, warmup, steps, sets=(0,)):
+        """K steps queued back to back (no host wait inside the timed region), `len(lists)` frames in flight; then the
+        kernel times of frames run one at a time (HIP events around one frame's kernels mean something only then)."""
+        if not isinstance(lists, (list, tuple)):
+            lists = [lists]
+        for _ in range(max(warmup, len(lists))):
+            step(lists, sets)
         trace("warm-up queued")
         eng.sync()
         eng.eval_count(reset=True)
         barrier()
         trace("timed region starts")
-        # HIP events bracket the kernels of the LAST step only: timestamp events drain the queue between
-        # launches, and with them in every step the back-to-back frames run a few per cent slower
         eng.set_timing(False)
         t0 = time.perf_counter()
         for k in range(steps):
-            if k == steps - 1:
-                eng.set_timing(True)
-            step(jl)
+            step(lists, sets)
         host_queue[0] = (time.perf_counter() - t0) / steps * 1e6      # the host's time to queue a step (no GPU wait in it)
         eng.sync()
         barrier()
         dt = time.perf_counter() - t0
         trace("timed region done")
-        k_full, k_search = eng.kernel_times()     # HIP events on the engine's streams around the last step's kernels
         evals = eng.eval_count()
+        # HIP events on the engine's streams around the kernels of ONE frame on an otherwise idle GPU (timestamp events drain
+        # the queue between launches, so they stay out of the timed region): median of five frames
+        eng.set_timing(True)
+        kt = []
+        for _ in range(5):
+            lists[0].run(enc_id, [ref_ids[0]], fetch=False)
+            eng.sync()
+            kt.append(eng.kernel_times())
+        # (timing stays on: the legs that time single calls read it)
+        k_full = float(np.median([a for a, _ in kt]))
+        k_search = float(np.median([b for _, b in kt]))
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,7 +429,7 @@ def main():
     run_hex = (world == 1) and not (args.only_primary and args.primary == "full")
     full = hexr = None
     if run_full:
-        fdt, fevals, k_full_ms, k_tail_ms = timed(jl_full, args.warmup, args.steps)
+        fdt, fevals, k_full_ms, k_tail_ms = timed(full_lists, args.warmup, args.steps, FULL_SETS)
         full_host_queue_us = host_queue[0]
         full_res = jl_full.run(enc_id, [ref_id], fetch=True)
         px_alg = pixel_sads(full_jobs)                    # 1 evaluation of a w x h block = w*h pixel-SADs, no credit for reuse
@@ -413,7 +437,7 @@ def main():
         full_bytes = alg_bytes + full_jobs.nbytes + len(full_jobs) * 8
         full = {
             "value": fevals / fdt, "ms_per_step": fdt / args.steps * 1e3, "frames_per_s": world * args.steps / fdt,
-            "evals_per_frame": fevals / (args.steps * world),
+            "evals_per_frame": fevals / (args.steps * world), "ms_per_frame_one_at_a_time": k_full_ms + k_tail_ms,
             "roofline": {"bound": "valu", "kernel": "k_full_hier", "achieved": px_exec / (k_full_ms * 1e-3) / 1e12, "peak": sad_peak / 1e12,
                          "unit": "T pixel-SAD/s", "frac": px_exec / (k_full_ms * 1e-3) / sad_peak,
                          "algorithmic_achieved": px_alg / (k_full_ms * 1e-3) / 1e12,
@@ -421,8 +445,14 @@ def main():
                          "traffic": pmc("k_full_hier_bytes_per_launch"), "traffic_source": TRAFFIC_SOURCE,
                          "kernel_ms": k_full_ms, "search_kernel_ms": k_tail_ms,
                          "kernel_ms_is": "HIP-event bracket on the engine's stream around the exhaustive kernels (k_pack_fenc + k_full_hier) "
-                                         "of the last step of the timed region; search_kernel_ms: the same around the search kernels "
+                                         "of ONE frame on an otherwise idle GPU (median of five frames run one at a time right after the "
+                                         "timed region; with several frames in flight a frame's kernels share the GPU with its neighbours' "
+                                         "and a bracket around them measures the mix); search_kernel_ms: the same around the search kernels "
                                          "(predictors, slab combine, half-pel SAD round, final SATD)",
+                         "frames_in_flight_frac": px_exec / (fdt / args.steps) / sad_peak,
+                         "frames_in_flight_frac_is": "executed pixel-SADs of a frame over ms_per_step (all of a frame's kernels, search "
+                                                     "kernels included, %d frames in flight) over the peak: the packed-SAD pipe's utilisation "
+                                                     "over the whole timed region" % depth_full,
                          "algorithmic_pixel_sads_per_launch": px_alg,
                          "executed_pixel_sads_per_launch": px_exec,
                          "note": "achieved / frac count the pixel-SADs the kernel EXECUTES (the 8x8 cells of every candidate, 3.4e10 per frame): "
@@ -436,7 +466,8 @@ def main():
                              "traffic_source": TRAFFIC_SOURCE},
         }
     if run_hex:
-        hdt, hevals, _, k_hex_ms = timed(jl_hex, args.warmup, args.steps)
+        hdt, hevals, _, k_hex_ms = timed(hex_lists, args.warmup, args.steps, HEX_SETS)
+        hdt1, _, _, _ = timed(jl_hex, 2, args.steps) if depth_hex > 1 else (hdt, 0, 0, 0)
         hex_res = jl_hex.run(enc_id, [ref_id], fetch=True)
         hex_bytes = alg_bytes + hex_jobs.nbytes + len(hex_jobs) * 8
         # algorithmic operations (1 SAD evaluation of a w x h block = w*h, 1 SATD evaluation = 5*w*h; the split
@@ -456,6 +487,7 @@ def main():
             "workload": "1080p 8-bit, HEX search merange 64 + subme 5 (8 half-pel + 8 quarter-pel SATD), PUs 16x16 + 64x64 "
                         "(BASELINE configs[1])",
             "value": hevals / hdt, "unit": "evals/s", "ms_per_frame": hdt / args.steps * 1e3, "frames_per_s": args.steps / hdt,
+            "frames_in_flight": depth_hex, "ms_per_frame_one_at_a_time": hdt1 / args.steps * 1e3,
             "jobs_per_frame": int(len(hex_jobs)), "evals_per_frame": hevals / args.steps,
             "satd_evals_per_frame": 17 * int(len(hex_jobs)), "sad_evals_per_frame": hevals / args.steps - 17 * int(len(hex_jobs)),
             # a search is a chain of dependent evaluation calls: instruction issue and per-call latency bind it,
@@ -504,7 +536,10 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": "1080p synthetic 8-bit, 64x64 CTUs, exhaustive +-64 integer search (SAD) of every square PU 64/32/16/8, "
-                               "subme 0 (BASELINE configs[0] on the GPU); one frame per GPU per step; reference plane broadcast from rank 0",
+                               "subme 0 (BASELINE configs[0] on the GPU); one frame per GPU per step, %d frames in flight per GPU (the searches of "
+                               "consecutive frames are independent, as on the reference's frame threads); reference plane broadcast from "
+                               "rank 0" % depth_full,
+                   "frames_in_flight": depth_full, "ms_per_frame_one_at_a_time": full["ms_per_frame_one_at_a_time"],
                    "jobs_per_frame": int(len(full_jobs)), "evals_per_frame": full["evals_per_frame"],
                    "qp": QP, "merange": MERANGE, "parallelism": "frames sharded over %d GPU(s)" % world,
                    # the collective alone, host-bracketed (it is also inside every timed step, beside the searches)
@@ -533,7 +568,7 @@ def main():
         if dist.is_initialized():
             ring = xd.PlaneRing(ref_bufs, engine=eng, src=0, overlap=bool(os.environ.get("X265AMD_OVERLAP")))
             step_no[0] = 0
-            cdt, _, _, _ = timed(jl_full, 3, 20)
+            cdt, _, _, _ = timed(full_lists, 3, 20, FULL_SETS)
             line["config"]["with_one_rank_group"] = {"process_group": group_backend, "ms_per_step": cdt / 20 * 1e3,
                                                      "host_queue_us_per_step": host_queue[0],
                                                      "host_queue_frac_of_step": host_queue[0] / (cdt / 20 * 1e6),
@@ -565,11 +600,12 @@ def main():
     # ---- the same frame with the diamond search (the other method BASELINE configs[1] names) ----
     dia_jobs = hex_jobs.copy()
     dia_jobs["method"] = J.DIA
-    jl_dia = eng.make_joblist(dia_jobs)
-    ddt, devals, _, k_dia_ms = timed(jl_dia, 2, args.steps)
-    jl_dia.close()
+    dia_lists = [eng.make_joblist(dia_jobs) for _ in range(depth_hex)]
+    ddt, devals, _, k_dia_ms = timed(dia_lists, 2, args.steps, HEX_SETS)
+    for j in dia_lists:
+        j.close()
     line["dia_search"] = {"workload": "same frame and PUs, DIA search + subme 5", "value": devals / ddt, "unit": "evals/s",
-                          "ms_per_frame": ddt / args.steps * 1e3, "kernel_ms": k_dia_ms}
+                          "ms_per_frame": ddt / args.steps * 1e3, "frames_in_flight": depth_hex, "kernel_ms": k_dia_ms}
 
     # ---- PCIe-inclusive: both planes uploaded and the MV/cost field downloaded every frame -------
     enc_pin = torch.from_numpy(enc_np).pin_memory()
@@ -635,7 +671,10 @@ def main():
     line["pcie_inclusive"]["pipelined"] = {"workload": "the same traffic with the frames pipelined: planes of frame k + 1 uploaded beside the search of "
                                                        "frame k (two plane sets, x265amd_plane_refill_async), field of frame k downloaded behind its search "
                                                        "into page-locked memory (x265amd_joblist_results_async); the host waits once at the end",
-                                           **piped, "vs_resident": piped["full_search"]["ms_per_frame"] / full["ms_per_step"]}
+                                           **piped, "vs_resident": piped["full_search"]["ms_per_frame"] / full["ms_per_step"],
+                                           "vs_resident_one_at_a_time": piped["full_search"]["ms_per_frame"] / full["ms_per_frame_one_at_a_time"],
+                                           "note": "one frame's searches at a time on the GPU (the uploads and downloads beside them); `value` has "
+                                                   "%d resident frames in flight" % depth_full}
     ok_pipe = all(v["field_equals_resident_run"] for v in piped.values())
 
     # ---- lookahead path (not part of `value`): half-resolution plane sets and whole-frame
@@ -671,7 +710,8 @@ def main():
     jl_hex.order_by_field(look_field, look_cw, look_ch)
     odt, _, _, k_ord_ms = timed(jl_hex, 2, args.steps)
     ord_res = jl_hex.run(enc_id, [ref_id], fetch=True)
-    line["hex_search"]["lookahead_ordered"] = {"ms_per_frame": odt / args.steps * 1e3, "kernel_ms": k_ord_ms,
+    line["hex_search"]["lookahead_ordered"] = {"ms_per_frame": odt / args.steps * 1e3, "kernel_ms": k_ord_ms, "frames_in_flight": 1,
+                                               "compare_with": "hex_search.ms_per_frame_one_at_a_time",
                                                "results_equal": bool(np.array_equal(ord_res, hex_res)),
                                                "note": "launch order from x265amd_lookahead_me's half-resolution field of the same frame pair "
                                                        "(x265amd_joblist_order_by_field); the lookahead's own time is in `lookahead`"}

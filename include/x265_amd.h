@@ -78,6 +78,10 @@ int  x265amd_debug_state(x265amd_ctx *ctx, char *buf, size_t n);
  * encoder/frameencoder.cpp:906-918). */
 int  x265amd_wait_event(x265amd_ctx *ctx, void *event);
 int  x265amd_record_event(x265amd_ctx *ctx, void *event);
+/* the same against the main stream of stream set `set` (x265amd_joblist_run_overlapped): orders one frame in flight
+ * against its own reference hand-over without holding up the frames on the other sets */
+int  x265amd_wait_event_on(x265amd_ctx *ctx, void *event, int set);
+int  x265amd_record_event_on(x265amd_ctx *ctx, void *event, int set);
 
 /* ---- planes --------------------------------------------------------------------------
  * A plane is a border-extended luma picture as TComPicYuv lays it out
@@ -281,16 +285,20 @@ int x265amd_joblist_create(x265amd_ctx *ctx, const x265amd_me_job *jobs, int n, 
  * X265AMD_ERR_RANGE as for x265amd_me_search_batch */
 int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,
                         x265amd_me_result *out);
-/* Two frames in flight.  x265amd_joblist_run(out = NULL) on stream set `set` of the context: 0 = the set every other
- * call uses, 1 = a second set on hardware queues of its own.  A run queued on set 1 executes beside the work queued on
- * set 0, so the workgroups of one frame's search fill the compute units that the end of the other frame's kernels leaves
- * idle (1080p exhaustive frame: 0.515 -> 0.45 ms per frame with lists alternating between the sets).  Each frame needs
- * its own list (a list's next run, on either set, starts behind its last one).  x265amd_sync waits for both sets;
- * x265amd_joblist_results / _results_async / _eval_counts wait for the list's last run wherever it ran; a pointer from
- * x265amd_joblist_results_device is valid after x265amd_sync.  Planes named by the call must be complete: a refill
- * queued with x265amd_plane_refill_async is waited for, any other write to a plane (x265amd_plane_update_rows, a caller's
- * own kernels on a wrapped plane) is ordered by the caller (x265amd_sync, or events) - work queued on set 0 is NOT awaited
- * by a run on set 1.  The reference runs the motion searches of several frames side by side on its frame threads
+/* Several frames in flight.  x265amd_joblist_run(out = NULL) on stream set `set` of the context.  The context owns four
+ * streams, each on a hardware queue of its own: set 0 = the main stream and its side stream, which every other call
+ * uses; set 1 = the other two; sets 2 and 3 = those pairs with main and side stream exchanged; sets 4 .. 7 = the main
+ * stream of set 0 .. 3 alone (the launches of one batch then follow each other instead of running side by side).
+ * Runs queued on different sets execute side by side, so the workgroups of one frame's search fill the compute units
+ * that the end of another frame's kernels leaves idle (MI355X, 1080p: exhaustive frames 0.514 ms one at a time, 0.446
+ * on sets 0 / 1 in turn, 0.42 on sets 4 .. 7 in turn; HEX + subme 5 frames 0.153 -> 0.098 on sets 0 / 1).  Each frame
+ * in flight needs its own list (a list's next run, on any set, starts behind its last one).  x265amd_sync waits for all
+ * sets; x265amd_joblist_results / _results_async / _eval_counts wait for the list's last run wherever it ran; a pointer
+ * from x265amd_joblist_results_device is valid after x265amd_sync.  The kernel times of x265amd_set_timing are those of
+ * runs one at a time only.  Planes named by the call must be complete: a refill queued with x265amd_plane_refill_async is
+ * waited for, any other write to a plane (x265amd_plane_update_rows, a caller's own kernels or collective on a wrapped
+ * plane) is ordered by the caller (x265amd_wait_event_on, x265amd_sync) - work queued on one set is NOT awaited by a run
+ * on another.  The reference runs the motion searches of several frames side by side on its frame threads
  * (encoder/encoder.cpp:199-203 `frameNumThreads`, encoder/frameencoder.cpp:285-300 FrameEncoder::threadMain ->
  * compressFrame: one thread per frame in flight, each reaching TEncSearch::predInterSearch). */
 int x265amd_joblist_run_overlapped(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, const int *ref_planes, int n_refs,

@@ -73,6 +73,8 @@ def load_library() -> C.CDLL:
     L.x265amd_debug_state.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.x265amd_wait_event.argtypes = [vp, vp]
     L.x265amd_record_event.argtypes = [vp, vp]
+    L.x265amd_wait_event_on.argtypes = [vp, vp, ci]
+    L.x265amd_record_event_on.argtypes = [vp, vp, ci]
     L.x265amd_plane_geometry.argtypes = [vp, ci, cip, cip, cip, cip, C.POINTER(C.c_ssize_t), cip, cip]
     L.x265amd_ipfilter.argtypes = [vp, ci, vp, C.c_ssize_t, vp, C.c_ssize_t, ci, ci, ci, ci, ci]
     L.x265amd_lookahead_status.argtypes = [vp]
@@ -171,13 +173,19 @@ class Engine:
         self.lib.x265amd_debug_state(self.h, buf, 512)
         return buf.value.decode()
 
-    def wait_event(self, event):
-        """work queued on the engine from now on starts after `event` (a torch.cuda.Event recorded on another stream)"""
-        self._chk(self.lib.x265amd_wait_event(self.h, event.cuda_event))
+    def wait_event(self, event, stream_set: int = 0):
+        """work queued on the engine (on stream set `stream_set`) from now on starts after `event` (a torch.cuda.Event
+        recorded on another stream)"""
+        self._chk(self.lib.x265amd_wait_event_on(self.h, event.cuda_event, stream_set))
 
-    def record_event(self, event):
-        """record `event` (a torch.cuda.Event) behind everything queued on the engine so far"""
-        event.record(self.torch_stream())
+    def record_event(self, event, stream_set: int = 0):
+        """record `event` (a torch.cuda.Event) behind everything queued on the engine's stream set so far"""
+        if stream_set == 0:
+            event.record(self.torch_stream())
+            return
+        if not event.cuda_event:            # (torch creates the HIP event at its first record)
+            event.record(self.torch_stream())
+        self._chk(self.lib.x265amd_record_event_on(self.h, event.cuda_event, stream_set))
 
     def plane_geometry(self, pid: int):
         """(width, height, margin_x, margin_y, stride, bytes_per_px, bit_depth)"""

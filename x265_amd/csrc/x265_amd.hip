@@ -137,8 +137,9 @@ struct x265amd_ctx
     hipStream_t out_stream = nullptr;
     x265amd_joblist *batch_list = nullptr;   // the host batch call's job list: its device buffers are kept between calls
     hipStream_t lane(int k) const { return (k % n_lanes) == 0 ? stream : aux[(k % n_lanes) - 1]; }
-    // Stream sets: set 0 = { stream, aux[0] }, set 1 = { aux[1], aux[2] }, each stream on a hardware queue of its own (the
-    // four are created back to back).  A batch queued on set 1 runs beside one queued on set 0 (x265amd_joblist_run_overlapped).
+    // Stream sets: set 0 = { stream, aux[0] }, set 1 = { aux[1], aux[2] }, sets 2 and 3 = those pairs with main and side
+    // stream exchanged.  The four streams are created back to back, so each has a hardware queue of its own, and batches
+    // queued on different sets run side by side (x265amd_joblist_run_overlapped).
     int cur_set = 0;
 };
 
@@ -146,28 +147,29 @@ struct x265amd_ctx
 struct StreamSet
 {
     x265amd_ctx *c;
-    int set, lanes;
-    StreamSet(x265amd_ctx *ctx, int s) : c(ctx), set(s), lanes(ctx->n_lanes)
+    int lanes;
+    hipStream_t s0, a0, a1, a2;
+    hipEvent_t j0, j1, j2;
+    StreamSet(x265amd_ctx *ctx, int set) : c(ctx), lanes(ctx->n_lanes), s0(ctx->stream), a0(ctx->aux[0]), a1(ctx->aux[1]), a2(ctx->aux[2]),
+                                           j0(ctx->ev_join[0]), j1(ctx->ev_join[1]), j2(ctx->ev_join[2])
     {
-        if (set)
-        {
-            std::swap(c->stream, c->aux[1]);
-            std::swap(c->aux[0], c->aux[2]);
-            std::swap(c->ev_join[0], c->ev_join[2]);
-            c->n_lanes = std::min(c->n_lanes, 2);
-            c->cur_set = 1;
-        }
+        if (!set)
+            return;
+        // (main, side, and the join event that belongs to the side stream)
+        hipStream_t m[4] = { s0, a1, a0, a2 }, sd[4] = { a0, a2, s0, a1 };
+        hipEvent_t jv[4] = { j0, j2, j1, j1 };       // (sets 2 and 3 record on what is another set's main stream: the spare event)
+        c->stream = m[set & 3];
+        c->aux[0] = sd[set & 3];
+        c->ev_join[0] = jv[set & 3];
+        c->n_lanes = set >= 4 ? 1 : std::min(c->n_lanes, 2);       // sets 4 .. 7: the main stream of set 0 .. 3 alone
+        c->cur_set = set;
     }
     ~StreamSet()
     {
-        if (set)
-        {
-            std::swap(c->stream, c->aux[1]);
-            std::swap(c->aux[0], c->aux[2]);
-            std::swap(c->ev_join[0], c->ev_join[2]);
-            c->n_lanes = lanes;
-            c->cur_set = 0;
-        }
+        c->stream = s0; c->aux[0] = a0; c->aux[1] = a1; c->aux[2] = a2;
+        c->ev_join[0] = j0; c->ev_join[1] = j1; c->ev_join[2] = j2;
+        c->n_lanes = lanes;
+        c->cur_set = 0;
     }
 };
 
@@ -1293,7 +1295,8 @@ int joblist_build(x265amd_ctx *c, x265amd_joblist *L, const x265amd_me_job *jobs
 void joblist_free(x265amd_ctx *c, x265amd_joblist *L)
 {
     hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->aux[1]);       // (a run on the second stream set)
+    for (int i = 0; i < x265amd_ctx::N_AUX; i++)
+        hipStreamSynchronize(c->aux[i]);   // (a run on another stream set)
     if (c->out_stream)
         hipStreamSynchronize(c->out_stream);
     if (L->ev_ran) hipEventDestroy(L->ev_ran);
@@ -1632,7 +1635,8 @@ int x265amd_sync(x265amd_ctx *c)
     if (!c)
         return X265AMD_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->aux[1]));               // runs on the second stream set
+    for (int i = 0; i < x265amd_ctx::N_AUX; i++)
+        HIPCHK(c, hipStreamSynchronize(c->aux[i]));           // runs on the other stream sets
     if (c->out_stream)
         HIPCHK(c, hipStreamSynchronize(c->out_stream));       // asynchronous result downloads
     if (c->up_stream)
@@ -1656,25 +1660,30 @@ int x265amd_debug_state(x265amd_ctx *c, char *buf, size_t n)
     return 0;
 }
 
-int x265amd_wait_event(x265amd_ctx *c, void *event)
+int x265amd_wait_event_on(x265amd_ctx *c, void *event, int set)
 {
-    if (!c || !event)
+    if (!c || !event || set < 0 || set > 7)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    StreamSet on(c, set);
     HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
     return 0;
 }
 
-int x265amd_record_event(x265amd_ctx *c, void *event)
+int x265amd_record_event_on(x265amd_ctx *c, void *event, int set)
 {
-    if (!c || !event)
+    if (!c || !event || set < 0 || set > 7)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    StreamSet on(c, set);
     HIPCHK(c, hipEventRecord((hipEvent_t)event, c->stream));
     return 0;
 }
+
+int x265amd_wait_event(x265amd_ctx *c, void *event) { return x265amd_wait_event_on(c, event, 0); }
+int x265amd_record_event(x265amd_ctx *c, void *event) { return x265amd_record_event_on(c, event, 0); }
 
 int x265amd_plane_geometry(x265amd_ctx *c, int id, int *width, int *height, int *margin_x, int *margin_y,
                            intptr_t *stride, int *bytes_per_px, int *bit_depth)
@@ -1825,7 +1834,7 @@ int x265amd_plane_refill_async(x265amd_ctx *c, int id, const void *host_base)
         HIPCHK(c, hipMemcpyAsync(c->base[id], host_base, bytes, hipMemcpyHostToDevice, c->up_stream));
     }
     HIPCHK(c, hipEventRecord(c->plane_filled[id], c->up_stream));
-    c->fill_pending[id] = 3;
+    c->fill_pending[id] = 255;
     return 0;
 }
 
@@ -2635,7 +2644,7 @@ int wait_list_done(x265amd_ctx *c, x265amd_joblist *L)
 static int joblist_run_on(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, const int *ref_planes, int n_refs,
                           x265amd_me_result *out, int set)
 {
-    if (!c || !L || set < 0 || set > 1)
+    if (!c || !L || set < 0 || set > 7)
         return X265AMD_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));

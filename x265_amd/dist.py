@@ -159,13 +159,14 @@ class PlaneRing:
             dist.broadcast(self.buffers[b], src=self.src)
         self.ready = k
 
-    def acquire(self, k: int) -> int:
+    def acquire(self, k: int, stream_set: int = 0) -> int:
+        """stream_set: the engine's stream set frame k's searches are queued on (frames in flight, one set each)"""
         b = self.slot(k)
         if self.collective:
             if self.ready < k:
                 self._broadcast(k)
             if self.gpu and self.filled[b] is not None:
-                self.engine.wait_event(self.filled[b])  # searches queued from now on see plane k
+                self.engine.wait_event(self.filled[b], stream_set)  # searches queued on that set from now on see plane k
                 self.filled[b] = None
         return b
 
@@ -173,12 +174,12 @@ class PlaneRing:
         if self.overlap and self.collective and self.ready < k:
             self._broadcast(k)
 
-    def release(self, k: int) -> None:
+    def release(self, k: int, stream_set: int = 0) -> None:
         if self.collective and self.gpu:
             b = self.slot(k)
             ev = self.free_pool[b][self.uses[b] & 1]
             self.uses[b] += 1
-            self.engine.record_event(ev)
+            self.engine.record_event(ev, stream_set)
             self.free[b] = ev
 
 
