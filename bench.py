@@ -495,6 +495,7 @@ def main():
             "roofline": {"bound": "valu", "kernel": "k_search<uint8_t>", "achieved": alg_ops / (k_hex_ms * 1e-3) / 1e12,
                          "peak": cus * 64 * clk_hz / 1e12, "unit": "T op/s", "frac": alg_ops / (k_hex_ms * 1e-3) / (cus * 64 * clk_hz),
                          "kernel_ms": k_hex_ms, "algorithmic_ops_per_launch": alg_ops,
+                         "frames_in_flight_frac": alg_ops / (hdt / args.steps) / (cus * 64 * clk_hz),
                          "ops_def": "SAD evaluation = w*h, SATD evaluation = 5*w*h integer operations"},
             "roofline_hbm": {"bound": "hbm", "kernel": "k_search<uint8_t>", "achieved": hex_bytes / (k_hex_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hex_bytes / (k_hex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -781,9 +782,23 @@ def main():
         ev = eng.eval_count() / steps
         k_ms, tail_ms = eng.kernel_times()
         res = jl.results()
+        # two frames in flight (a second list, stream sets 0 / 1)
+        jl2 = eng.make_joblist(jobs, bytes_per_px=2)
+        pair = (jl, jl2)
+        for k in range(2):
+            pair[k].run_overlapped(ids4[1], [ids4[0]], k)
+        eng.sync()
+        t0 = time.perf_counter()
+        for k in range(steps + (steps & 1)):
+            pair[k & 1].run_overlapped(ids4[1], [ids4[0]], k & 1)
+        eng.sync()
+        dt2 = (time.perf_counter() - t0) / (steps + (steps & 1))
+        same = bool(np.array_equal(jl2.results(), res))
         jl.close()
+        jl2.close()
         return res, {"jobs_per_frame": int(len(jobs)), "evals_per_frame": ev, "value": ev / dt, "unit": "evals/s",
-                     "ms_per_frame": dt * 1e3, "kernel_ms": k_ms, "search_kernel_ms": tail_ms}
+                     "ms_per_frame": dt * 1e3, "kernel_ms": k_ms, "search_kernel_ms": tail_ms,
+                     "two_in_flight": {"ms_per_frame": dt2 * 1e3, "value": ev / dt2, "unit": "evals/s", "results_equal": same}}
 
     all_res, line["sa8d_full_4k10"]["all_partitions"] = run_4k10(all_jobs, 5)
     line["sa8d_full_4k10"]["all_partitions"]["workload"] = "the 209 partitions of every CTU that are made of 8x8 cells (85 squares + 124 rectangles)"

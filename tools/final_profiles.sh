@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round profile set, run on the GPU box from the repository root:  bash tools/final_profiles.sh <tag>
 #   1. rocprofv3 --kernel-trace --stats of the default bench.py (all legs)     -> gpurun_out/<tag>_kernel_stats_bench.csv (+ log)
-#   2. the same of `bench.py --only-primary` (FULL +-64 leg alone) and of `--only-primary --primary hex`
-#      -> gpurun_out/<tag>_kernel_stats_{full,hex}_leg.csv, <tag>_kernel_trace_{full,hex}_leg.csv, <tag>_union_spans.txt
+#   2. the same of `bench.py --only-primary --in-flight 1` (FULL +-64 leg alone, one frame at a time) and of `--only-primary
+#      --primary hex --in-flight 1` -> gpurun_out/<tag>_kernel_stats_{full,hex}_leg.csv, <tag>_kernel_trace_{full,hex}_leg.csv,
+#      <tag>_union_spans.txt; and of `bench.py --only-primary` (four frames in flight) -> <tag>_kernel_stats_full_leg_in_flight.csv
 #   3. HBM traffic counters (FETCH_SIZE / WRITE_SIZE, one pass each) of both legs -> gpurun_out/<tag>_pmc_traffic.json
 # Copy the files you want kept from gpurun_out/ into profiles/ (pmc_traffic.json is what bench.py reads).
 set -u
@@ -20,20 +21,42 @@ run_stats() {   # name, bench arguments...
     return 0
 }
 run_stats bench --steps 20 --warmup 3 --no-cpu || exit 1
-run_stats full_leg --steps 20 --warmup 3 --only-primary || exit 1
-run_stats hex_leg --steps 20 --warmup 3 --only-primary --primary hex || exit 1
+# one frame at a time: a dispatch's duration is then the kernel's own (with frames in flight it shares the GPU)
+run_stats full_leg --steps 20 --warmup 3 --only-primary --in-flight 1 || exit 1
+run_stats hex_leg --steps 20 --warmup 3 --only-primary --primary hex --in-flight 1 || exit 1
+# the headline as bench.py runs it (four frames in flight)
+run_stats full_leg_in_flight --steps 40 --warmup 4 --only-primary || exit 1
 {
     echo "== FULL +-64 leg: exhaustive kernels (k_pack_fenc + k_full_hier), then the general and group-per-job kernels' launches of one step"
     python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_full_leg.csv k_pack_fenc,k_full_hier
     python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_full_leg.csv k_search,k_lane
     echo "== HEX + subme 5 leg: the general kernel's launches and the group-per-job kernel of one step (side by side)"
     python3 $R/tools/union_span.py $R/gpurun_out/${TAG}_kernel_trace_hex_leg.csv k_search,k_lane
+    echo "== FULL +-64 leg with four frames in flight: busy span of all search kernels over the dispatches of the run"
+    python3 - $R/gpurun_out/${TAG}_kernel_trace_full_leg_in_flight.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in ("k_full_hier", "k_pack_fenc", "k_search", "k_lane"))]
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+n_frames = sum(1 for r in rows if "k_full_hier" in r["Kernel_Name"])
+# the last 40 frames (the timed region and the five one-at-a-time frames behind it are in the trace too: take the longest gap-free stretch)
+busy, cur_s, cur_e, spans = 0, None, None, []
+for s, e in iv:
+    if cur_e is None or s > cur_e + 20000:
+        if cur_e is not None: spans.append((cur_s, cur_e))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+spans.append((cur_s, cur_e))
+ls, le = max(spans, key=lambda p: p[1] - p[0])
+inside = sum(1 for r in rows if "k_full_hier" in r["Kernel_Name"] and ls <= int(r["Start_Timestamp"]) <= le)
+print("%d k_full_hier dispatches in the trace; longest gap-free stretch: %.3f ms with %d of them -> %.4f ms per frame" % (n_frames, (le - ls) / 1e6, inside, (le - ls) / 1e6 / max(inside, 1)))
+PY
 } > $R/gpurun_out/${TAG}_union_spans.txt 2>&1
 cat $R/gpurun_out/${TAG}_union_spans.txt
 for leg in full hex; do
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf $R/gpurun_out/pmc_${leg}_$c
-        timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${leg}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --only-primary --primary $leg > $R/gpurun_out/pmc_${leg}_$c.log 2>&1 || { echo "pass $leg $c failed"; tail -5 $R/gpurun_out/pmc_${leg}_$c.log; exit 1; }
+        timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${leg}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --only-primary --in-flight 1 --primary $leg > $R/gpurun_out/pmc_${leg}_$c.log 2>&1 || { echo "pass $leg $c failed"; tail -5 $R/gpurun_out/pmc_${leg}_$c.log; exit 1; }
     done
 done
 python3 - $R $TAG <<'PY'

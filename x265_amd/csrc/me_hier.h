@@ -41,6 +41,7 @@ static __device__ unsigned long long g_hier_trace[3 * 16384];   // per work item
 #define XA_HIER_THREADS 128
 #endif
 constexpr int HIER_R = XA_HIER_R;                 // candidate rows per lane task
+static_assert(4 * HIER_R <= 32, "hier_lane_min64 keeps the slot of a lane's candidate in 5 bits");
 constexpr int HIER_THREADS = XA_HIER_THREADS;
 constexpr int HIER_WAVES = HIER_THREADS / 64;
 constexpr int HIER_SLOT_ROWS = 4;         // winner slots of a small PU per wavefront: one per 16-lane row
@@ -240,7 +241,7 @@ __device__ __forceinline__ uint32_t hier_lane_min32(const unsigned long long *p,
 
 // The lane's best candidate of a 32x32 / 64x64 PU from 32-bit sums, as a 64-bit key (cost << 32 | raster index) for
 // the cross-lane reduction; column / row terms as above (only their cost fields and "at or above HIER_KEY_NONE" are
-// used).  Inside the lane the 4 x HIER_R candidates are compared as (cost << 4 | slot), slot = 4 * row + x being their
+// used).  Inside the lane the 4 x HIER_R candidates are compared as (cost << 5 | slot), slot = 4 * row + x being their
 // raster order.
 __device__ __forceinline__ unsigned long long hier_lane_min64(const uint32_t (*s)[4], const uint32_t *cxk, const uint32_t *cyk,
                                                               int x0, int y0, int nxw)
@@ -254,10 +255,10 @@ __device__ __forceinline__ unsigned long long hier_lane_min64(const uint32_t (*s
         {
             const uint32_t t = hier_add_sat(cxk[x], cyk[i]);
             const uint32_t mv = t < HIER_KEY_NONE ? t >> HIER_RIDX_BITS : BIG;
-            const uint32_t k = ((s[i][x] + mv) << 4) | (uint32_t)(i * 4 + x);
+            const uint32_t k = ((s[i][x] + mv) << 5) | (uint32_t)(i * 4 + x);
             m = k < m ? k : m;
         }
-    const uint32_t cost = m >> 4, slot = m & 15;
+    const uint32_t cost = m >> 5, slot = m & 31;
     if (cost >= BIG)
         return ~0ull;
     return ((unsigned long long)cost << 32) | (uint32_t)((y0 + (int)(slot >> 2)) * nxw + x0 + (int)(slot & 3));
