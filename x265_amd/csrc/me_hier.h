@@ -44,6 +44,10 @@ constexpr int HIER_R = XA_HIER_R;                 // candidate rows per lane tas
 static_assert(4 * HIER_R <= 32, "hier_lane_min64 keeps the slot of a lane's candidate in 5 bits");
 constexpr int HIER_THREADS = XA_HIER_THREADS;
 constexpr int HIER_WAVES = HIER_THREADS / 64;
+#ifndef XA_HIER_PF
+#define XA_HIER_PF 4
+#endif
+constexpr int HIER_PF = XA_HIER_PF;        // window rows of the next cell fetched into registers a cell ahead
 constexpr int HIER_SLOT_ROWS = 4;         // winner slots of a small PU per wavefront: one per 16-lane row
 constexpr int HIER_PUS = 85;              // 64 + 16 + 4 + 1 squares of the quadtree
 constexpr int HIER_SMALL = 80;            // PUs 0..79 (8x8, 16x16) use 32-bit keys
@@ -501,13 +505,15 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             for (int e = 0; e < 16; e++)
                 f[e] = fe[e];
         }
-        unsigned long long w[8 + R - 1][2];     // window rows of the cell: dword pairs (k, k + 1) and (k + 1, k + 2)
+        // (HIER_PF of the cell's 8 + R - 1 window rows are fetched a cell ahead; the others follow while the first ones are measured)
+        unsigned long long w[HIER_PF][2];       // window rows of the cell: dword pairs (k, k + 1) and (k + 1, k + 2)
+        const uint32_t *row;
         {
             int cx, cy;
             hier_cell_xy(z & 63, cx, cy);
-            const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
+            row = wbase + (cy * 8) * pitch + cx * 2;
 #pragma unroll
-            for (int r = 0; r < 8 + R - 1; r++)
+            for (int r = 0; r < HIER_PF; r++)
             {
                 w[r][0] = lds_pair(row + r * pitch);
                 w[r][1] = lds_pair(row + r * pitch + 1);
@@ -532,14 +538,16 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 #pragma unroll
             for (int r = 0; r < 8 + R - 1; r++)
             {
+                const unsigned long long d0 = r < HIER_PF ? w[r][0] : lds_pair(row + r * pitch);
+                const unsigned long long d1 = r < HIER_PF ? w[r][1] : lds_pair(row + r * pitch + 1);
 #pragma unroll
                 for (int i = 0; i < R; i++)
                 {
                     const int e = r - i;            // encoder row that window row r meets in candidate row i
                     if (e >= 0 && e < 8)
                     {
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[r][0], f[2 * e], p[i]);
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[r][1], f[2 * e + 1], p[i]);
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d0, f[2 * e], p[i]);
+                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d1, f[2 * e + 1], p[i]);
                     }
                 }
             }
@@ -547,9 +555,9 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
             {
                 int cx, cy;
                 hier_cell_xy(nz & 63, cx, cy);
-                const uint32_t *row = wbase + (cy * 8) * pitch + cx * 2;
+                row = wbase + (cy * 8) * pitch + cx * 2;
 #pragma unroll
-                for (int r = 0; r < 8 + R - 1; r++)
+                for (int r = 0; r < HIER_PF; r++)
                 {
                     w[r][0] = lds_pair(row + r * pitch);
                     w[r][1] = lds_pair(row + r * pitch + 1);
