@@ -48,6 +48,10 @@ constexpr int HIER_WAVES = HIER_THREADS / 64;
 #define XA_HIER_PF 4
 #endif
 constexpr int HIER_PF = XA_HIER_PF;        // window rows of the next cell fetched into registers a cell ahead
+#ifndef XA_HIER_WPS
+#define XA_HIER_WPS 4
+#endif
+constexpr int HIER_WAVES_PER_SIMD = XA_HIER_WPS;   // occupancy the kernel is compiled for
 constexpr int HIER_SLOT_ROWS = 4;         // winner slots of a small PU per wavefront: one per 16-lane row
 constexpr int HIER_PUS = 85;              // 64 + 16 + 4 + 1 squares of the quadtree
 constexpr int HIER_SMALL = 80;            // PUs 0..79 (8x8, 16x16) use 32-bit keys
@@ -341,6 +345,30 @@ __device__ __forceinline__ void hier_pred_terms(const uint32_t *s_tx, const uint
     }
 }
 
+// One 8x8 cell against the lane's 4 x RL candidates: window row r meets encoder row r - i in candidate row i.  w holds the first
+// HIER_PF window rows (fetched a cell ahead), the others are read here; p[i] = packed 16-bit SADs of row i's 4 candidates.
+template <int RL>
+__device__ __forceinline__ void hier_measure(const unsigned long long (*w)[2], const uint32_t *row, int pitch, const uint32_t *f,
+                                             unsigned long long *p)
+{
+#pragma unroll
+    for (int r = 0; r < 8 + RL - 1; r++)
+    {
+        const unsigned long long d0 = r < HIER_PF ? w[r][0] : lds_pair(row + r * pitch);
+        const unsigned long long d1 = r < HIER_PF ? w[r][1] : lds_pair(row + r * pitch + 1);
+#pragma unroll
+        for (int i = 0; i < RL; i++)
+        {
+            const int e = r - i;
+            if (e >= 0 && e < 8)
+            {
+                p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d0, f[2 * e], p[i]);
+                p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d1, f[2 * e + 1], p[i]);
+            }
+        }
+    }
+}
+
 // MODE 0: one predictor, every job's range is the window; 1: one predictor, per-job ranges; 2: per-job predictors, every job's
 // range is the same around its predictor; 3: per-job predictors and ranges
 template <int MODE, bool KEYS>
@@ -453,10 +481,19 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
     const uint64_t has8 = __ballot(B.job[lane] >= 0);
     const uint32_t hasb = (uint32_t)__ballot(lane < HIER_PUS - 64 && B.job[64 + (lane < HIER_PUS - 64 ? lane : 0)] >= 0);
     const uint64_t cells = B.cells;
+    // The last task row of a window of 4 k + 1 candidate rows (+-64, +-16: 129, 33) holds ONE candidate row: a wavefront whose
+    // lane tasks all lie in it measures that row only (a quarter of the quad-SADs).  A work item that straddles the start of
+    // that task row gives it to its last wavefront and the tasks before it to the first.
+    const int n_trows = (nyw + R - 1) / R, bottom0 = (n_trows - 1) * XG;
+    const bool thin = R > 1 && nyw - R * (n_trows - 1) == 1;
+    const bool split = thin && it.t_lo < bottom0 && bottom0 < it.t_hi && bottom0 - it.t_lo <= 64 * (HIER_WAVES - 1) && it.t_hi - bottom0 <= 64;
+    const int swv = __builtin_amdgcn_readfirstlane(wv);
     for (int base = it.t_lo; base < it.t_hi; base += HIER_THREADS)
     {
-        const int task = base + tid;
-        const bool active = task < it.t_hi;
+        const int wave_first = split ? (swv == HIER_WAVES - 1 ? bottom0 : it.t_lo + 64 * swv) : base + 64 * swv;
+        const int task = wave_first + lane;
+        const bool active = task < (split && swv != HIER_WAVES - 1 ? bottom0 : it.t_hi);
+        const bool one_row = thin && wave_first >= bottom0;
         const int tk = active ? task : it.t_lo;
         const int yq = tk / XG, xg = tk - yq * XG;
         const int x0 = 4 * xg, y0 = R * yq;
@@ -506,7 +543,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
                 f[e] = fe[e];
         }
         // (HIER_PF of the cell's 8 + R - 1 window rows are fetched a cell ahead; the others follow while the first ones are measured)
-        unsigned long long w[HIER_PF][2];       // window rows of the cell: dword pairs (k, k + 1) and (k + 1, k + 2)
+        unsigned long long w[HIER_PF ? HIER_PF : 1][2];     // window rows of the cell: dword pairs (k, k + 1) and (k + 1, k + 2)
         const uint32_t *row;
         {
             int cx, cy;
@@ -535,22 +572,10 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 #pragma unroll
             for (int i = 0; i < R; i++)
                 p[i] = 0;
-#pragma unroll
-            for (int r = 0; r < 8 + R - 1; r++)
-            {
-                const unsigned long long d0 = r < HIER_PF ? w[r][0] : lds_pair(row + r * pitch);
-                const unsigned long long d1 = r < HIER_PF ? w[r][1] : lds_pair(row + r * pitch + 1);
-#pragma unroll
-                for (int i = 0; i < R; i++)
-                {
-                    const int e = r - i;            // encoder row that window row r meets in candidate row i
-                    if (e >= 0 && e < 8)
-                    {
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d0, f[2 * e], p[i]);
-                        p[i] = __builtin_amdgcn_qsad_pk_u16_u8(d1, f[2 * e + 1], p[i]);
-                    }
-                }
-            }
+            if (one_row)
+                hier_measure<1>(w, row, pitch, f, p);       // (the other rows' sums stay 0 and their keys are struck out)
+            else
+                hier_measure<R>(w, row, pitch, f, p);
             asm volatile("" ::: "memory");      // (the reads below start before the pricing, not behind it)
             {
                 int cx, cy;
@@ -722,7 +747,7 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
 // formed on the device - `items` is the offsets array described above, n_items the number of cells, a job's slabs meet in
 // one 64-bit key, and fb_stride = -(LDS size class of this launch, plan_lds_class): every class has a launch of its own.
 template <bool KEYS>
-__global__ void __launch_bounds__(HIER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
+__global__ void __launch_bounds__(HIER_THREADS) __attribute__((amdgpu_waves_per_eu(HIER_WAVES_PER_SIMD, HIER_WAVES_PER_SIMD))) k_full_hier(BatchParams P, const x265amd_me_job *jobs, const HierBundle *bundles,
                                                             const HierItem *items, int n_items, const uint32_t *packed,
                                                             FullBest *fb, int fb_stride)
 {
