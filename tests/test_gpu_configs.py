@@ -172,8 +172,11 @@ def _single_rank_group():
     raise last
 
 
-def test_4k_lookahead_batch_through_plane_ring(oracle):
-    """BASELINE's 4K 8-frame lookahead batch on the rank that would own all of it: the frames of the
+@pytest.mark.parametrize("in_flight", [1, 2, 4])
+def test_4k_lookahead_batch_through_plane_ring(oracle, in_flight):
+    """(in_flight > 1: the frames take the engine's stream sets in turn - two-stream sets 0 / 1 or single-stream sets 4 .. 7 -
+    and every hand-over of the ring goes to the set of the frame it belongs to.)
+    BASELINE's 4K 8-frame lookahead batch on the rank that would own all of it: the frames of the
     batch are searched one after the other, each against the reference plane that arrives through
     PlaneRing (broadcast into one of two device buffers wrapped with x265amd_plane_wrap_device, the
     next plane's broadcast queued beside the current frame's searches, all hand-overs stream events).
@@ -211,15 +214,20 @@ def test_4k_lookahead_batch_through_plane_ring(oracle):
         # buffer it is about to broadcast, once the searches still reading that buffer are done
         ring.publish(k, host_refs[k & 1])
 
+    sets = {1: (0,), 2: (0, 1), 4: (4, 5, 6, 7)}[in_flight]
     publish(0)
     for k in range(NF):                     # nothing in this loop waits on the host
-        b = ring.acquire(k)
+        st = sets[k % len(sets)]
+        b = ring.acquire(k, st)
         assert b == (k & 1)
-        jls[k].run(enc_ids[k], [buf_ids[b]], fetch=False)
+        if in_flight == 1:
+            jls[k].run(enc_ids[k], [buf_ids[b]], fetch=False)
+        else:
+            jls[k].run_overlapped(enc_ids[k], [buf_ids[b]], st)
         if k + 1 < NF:
             publish(k + 1)
             ring.prefetch(k + 1)
-        ring.release(k)
+        ring.release(k, st)
     eng.sync()
     for k in range(NF):
         got = jls[k].results()
