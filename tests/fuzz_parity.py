@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer aid: a long randomised parity campaign of the search entry points against the CPU restatement
 (oracle/libme_oracle.so, the checker the tests use).  Random frame sizes, contents, bit depths, PU shapes, methods,
-sub-pel levels, predictors, ranges and cost kinds; every batch goes through the host-batch call AND a planned job list.
+sub-pel levels, predictors, ranges and cost kinds; every batch goes through the host-batch call, a planned job list, and two
+planned lists in flight on two of the engine's stream sets.
 
     python tests/fuzz_parity.py [seconds] [seed]      (default 240 s)
 
@@ -77,10 +78,18 @@ while time.time() - t0 < budget:
     got = eng.search(ids[0], [ids[1], ids[2]], jobs)
     jl = eng.make_joblist(jobs, n_refs=2, bytes_per_px=fr[0].itemsize)
     got2 = jl.run(ids[0], [ids[1], ids[2]])
+    # ... and with frames in flight: the same list and a second one queued on a random pair of the engine's stream sets
+    jl_b = eng.make_joblist(jobs, n_refs=2, bytes_per_px=fr[0].itemsize)
+    sa, sb = [(0, 1), (4, 5), (6, 7), (2, 3), (5, 0)][int(rng.integers(0, 5))]
+    for rep in range(2):
+        jl.run_overlapped(ids[0], [ids[1], ids[2]], sa)
+        jl_b.run_overlapped(ids[0], [ids[1], ids[2]], sb)
+    got3, got4 = jl.results(), jl_b.results()
     jl.close()
+    jl_b.close()
     for i in ids:
         eng.release_plane(i)
-    for name, g in (("host batch", got), ("job list", got2)):
+    for name, g in (("host batch", got), ("job list", got2), ("job list, stream set %d" % sa, got3), ("second job list, stream set %d" % sb, got4)):
         bad = np.nonzero(g != exp)[0]
         if bad.size:
             print("MISMATCH (%s): mode %d bits %d depth %d %dx%d %s: %d of %d jobs; first: %s got %s want %s"
