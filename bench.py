@@ -636,21 +636,25 @@ def main():
     # k + 1 are refilled through the library (x265amd_plane_refill_async: behind the searches queued so far, beside the search of
     # frame k) and the field of frame k comes down behind its search (x265amd_joblist_results_async into page-locked memory);
     # the host waits once at the end
-    sets = [{"enc_id": eng.upload_plane(enc_np), "ref_id": eng.upload_plane(ref_np)} for _ in range(2)]
+    PD, PP, PA = (2, 4, 2) if depth_full > 1 else (1, 2, 1)     # frames in flight, plane slots, frames a refill runs ahead
+    sets = [{"enc_id": eng.upload_plane(enc_np), "ref_id": eng.upload_plane(ref_np)} for _ in range(PP)]
     piped = {}
-    for name, jobs_np, ev in (("full_search", full_jobs, full["evals_per_frame"]), ("hex_search", hex_jobs, hexr["evals_per_frame"])):
-        jls = [eng.make_joblist(jobs_np) for _ in range(2)]
-        outs = [torch.zeros(len(jobs_np) * 8, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    for name, jobs_np, ev, psets in (("full_search", full_jobs, full["evals_per_frame"], (4, 5)), ("hex_search", hex_jobs, hexr["evals_per_frame"], (0, 1))):
+        jls = [eng.make_joblist(jobs_np) for _ in range(PD)]
+        outs = [torch.zeros(len(jobs_np) * 8, dtype=torch.uint8).pin_memory() for _ in range(PD)]
 
         def frame(k):
-            nxt = sets[(k + 1) & 1]
+            nxt = sets[(k + PA) % PP]
             eng.refill_plane_async(nxt["enc_id"], enc_pin.data_ptr())
             eng.refill_plane_async(nxt["ref_id"], ref_pin.data_ptr())
-            st = sets[k & 1]
-            jls[k & 1].run(st["enc_id"], [st["ref_id"]], fetch=False)
-            jls[k & 1].results_async(outs[k & 1].data_ptr())
+            st = sets[k % PP]
+            if PD > 1:
+                jls[k % PD].run_overlapped(st["enc_id"], [st["ref_id"]], psets[k % PD])
+            else:
+                jls[0].run(st["enc_id"], [st["ref_id"]], fetch=False)
+            jls[k % PD].results_async(outs[k % PD].data_ptr())
 
-        for k in range(4):
+        for k in range(2 * PP):
             frame(k)
         eng.sync()
         barrier()
@@ -660,8 +664,7 @@ def main():
         eng.sync()
         barrier()
         d = time.perf_counter() - t0
-        got = outs[(args.steps - 1) & 1].numpy().view(J.RESULT_DTYPE)
-        same = bool(np.array_equal(got, full_res if name == "full_search" else hex_res))
+        same = all(bool(np.array_equal(o.numpy().view(J.RESULT_DTYPE), full_res if name == "full_search" else hex_res)) for o in outs)
         piped[name] = {"ms_per_frame": d / args.steps * 1e3, "frames_per_s": args.steps / d, "value": ev * args.steps / d, "unit": "evals/s",
                        "field_equals_resident_run": same}
         for j in jls:
@@ -669,13 +672,15 @@ def main():
     for st in sets:
         eng.release_plane(st["enc_id"])
         eng.release_plane(st["ref_id"])
-    line["pcie_inclusive"]["pipelined"] = {"workload": "the same traffic with the frames pipelined: planes of frame k + 1 uploaded beside the search of "
-                                                       "frame k (two plane sets, x265amd_plane_refill_async), field of frame k downloaded behind its search "
-                                                       "into page-locked memory (x265amd_joblist_results_async); the host waits once at the end",
+    line["pcie_inclusive"]["pipelined"] = {"workload": "the same traffic with the frames pipelined: %d frames in flight on their own stream sets, %d plane "
+                                                       "slots, the planes of frame k + %d uploaded beside the searches of frames k and k + 1 "
+                                                       "(x265amd_plane_refill_async: behind the readers of its slot on every set), the field of "
+                                                       "frame k downloaded on its own set behind its search into page-locked memory "
+                                                       "(x265amd_joblist_results_async); the host waits once at the end" % (PD, PP, PA),
+                                           "frames_in_flight": PD,
                                            **piped, "vs_resident": piped["full_search"]["ms_per_frame"] / full["ms_per_step"],
                                            "vs_resident_one_at_a_time": piped["full_search"]["ms_per_frame"] / full["ms_per_frame_one_at_a_time"],
-                                           "note": "one frame's searches at a time on the GPU (the uploads and downloads beside them); `value` has "
-                                                   "%d resident frames in flight" % depth_full}
+                                           "note": "`value` has %d resident frames in flight" % depth_full}
     ok_pipe = all(v["field_equals_resident_run"] for v in piped.values())
 
     # ---- lookahead path (not part of `value`): half-resolution plane sets and whole-frame

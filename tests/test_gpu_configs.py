@@ -269,3 +269,44 @@ def test_planes_refilled_and_fields_fetched_asynchronously(eng, oracle):
     for st in sets:
         eng.release_plane(st["enc"])
         eng.release_plane(st["ref"])
+
+
+@pytest.mark.parametrize("sets", [(4, 5), (0, 1), (5, 6, 7)])
+def test_refills_and_downloads_with_frames_in_flight(eng, oracle, sets):
+    """The same pipeline with several frames in flight: frame k runs on stream set sets[k mod D] (one list per set, reused
+    every D frames), its planes live in one of D + 2 plane slots refilled two frames ahead, its field comes down on its own
+    set.  A refill waits for the readers of its slot on EVERY set and a run for the refill of its planes; every field must be
+    the oracle's for that frame's pictures."""
+    import torch
+    W, H, NF = 416, 240, 12
+    D, P, AHEAD = len(sets), len(sets) + 2, 2
+    fr = synth.make_sequence(W, H, NF + 1, seed=43)
+    pins = [torch.from_numpy(f).pin_memory() for f in fr]
+    jobs = np.concatenate([J.frame_jobs(W, H, sizes=(64, 32, 16, 8), method=J.FULL, subme=1, merange=24, qp=30),
+                           J.frame_jobs(W, H, sizes=(16, 8), method=J.HEX, subme=5, merange=32, qp=30)])
+    slots = [{"enc": eng.create_plane(W, H), "ref": eng.create_plane(W, H)} for _ in range(P)]
+    lists = [eng.make_joblist(jobs) for _ in range(D)]
+    outs = [torch.zeros(len(jobs) * 8, dtype=torch.uint8).pin_memory() for _ in range(NF)]
+
+    def refill(k):                          # the pictures of frame k: picture k + 1 against picture k
+        eng.refill_plane_async(slots[k % P]["enc"], pins[k + 1].data_ptr())
+        eng.refill_plane_async(slots[k % P]["ref"], pins[k].data_ptr())
+
+    for k in range(AHEAD):
+        refill(k)
+    for k in range(NF):                     # nothing in this loop waits on the host
+        if k + AHEAD < NF:
+            refill(k + AHEAD)
+        st = slots[k % P]
+        lists[k % D].run_overlapped(st["enc"], [st["ref"]], sets[k % D])
+        lists[k % D].results_async(outs[k].data_ptr())
+    eng.sync()
+    for k in range(NF):
+        exp, _ = oracle.search(fr[k + 1], [fr[k]], jobs, threads=8)
+        got = outs[k].numpy().view(J.RESULT_DTYPE)
+        assert np.array_equal(got, exp), (k, np.nonzero(got != exp)[0][:5])
+    for jl in lists:
+        jl.close()
+    for st in slots:
+        eng.release_plane(st["enc"])
+        eng.release_plane(st["ref"])

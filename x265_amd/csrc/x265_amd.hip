@@ -131,6 +131,10 @@ struct x265amd_ctx
     bool        up_stream_owned = false;
     hipEvent_t  ev_mark = nullptr;
     hipEvent_t  plane_filled[MAX_PLANES] = {};
+    // per plane and stream set: behind the last run on that set that named the plane (sets 0 and 4 run on the main stream, which a
+    // refill orders itself behind anyway); read_pending bit s: a refill of the plane has to wait for plane_read[.][s]
+    hipEvent_t  plane_read[MAX_PLANES][8] = {};
+    unsigned char read_pending[MAX_PLANES] = {};
     unsigned char fill_pending[MAX_PLANES] = {};   // bit s: stream set s has not yet waited for the plane's last refill
     // results leave on a stream of their own (x265amd_joblist_results_async), so that a download does not hold up the
     // next batch on the main stream; created on first use
@@ -1622,8 +1626,13 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->out_stream) hipStreamDestroy(c->out_stream);
     for (int i = 0; i < MAX_PLANES; i++)
+    {
         if (c->plane_filled[i])
             hipEventDestroy(c->plane_filled[i]);
+        for (int st = 0; st < 8; st++)
+            if (c->plane_read[i][st])
+                hipEventDestroy(c->plane_read[i][st]);
+    }
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1819,6 +1828,11 @@ int x265amd_plane_refill_async(x265amd_ctx *c, int id, const void *host_base)
     // that does not name this plane
     HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->ev_mark, 0));
+    // ... and behind the runs on the other stream sets that named this plane
+    for (int st = 0; st < 8; st++)
+        if (c->read_pending[id] & (1u << st))
+            HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->plane_read[id][st], 0));
+    c->read_pending[id] = 0;
     const size_t bytes = (size_t)(d.hi - d.lo) * d.bpp;
     void *mapped = nullptr;
     if (hipHostGetDevicePointer(&mapped, const_cast<void*>(host_base), 0) == hipSuccess && mapped)
@@ -1852,9 +1866,12 @@ int x265amd_plane_release(x265amd_ctx *c, int id)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < x265amd_ctx::N_AUX; i++)
+        HIPCHK(c, hipStreamSynchronize(c->aux[i]));           // (runs on the other stream sets may read the plane)
     if (c->up_stream)
         HIPCHK(c, hipStreamSynchronize(c->up_stream));
     c->fill_pending[id] = 0;
+    c->read_pending[id] = 0;
     if (c->owned[id])
         hipFree(c->owned[id]);
     c->used[id] = false;
@@ -2679,6 +2696,15 @@ static int joblist_run_on(x265amd_ctx *c, x265amd_joblist *L, int enc_plane, con
     if (int rc = joblist_launch(c, L, P)) return rc;
     HIPCHK(c, hipEventRecord(L->ev_done, c->stream));
     L->last_set = set;
+    if (set != 0 && set != 4)
+        for (int k = -1; k < n_refs; k++)
+        {
+            const int id = k < 0 ? enc_plane : ref_planes[k];
+            if (!c->plane_read[id][set])
+                HIPCHK(c, hipEventCreateWithFlags(&c->plane_read[id][set], hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->plane_read[id][set], c->stream));
+            c->read_pending[id] |= (unsigned char)(1u << set);
+        }
     if (out)
     {
         HIPCHK(c, hipMemcpyAsync(out, L->results.p, (size_t)L->n * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, c->stream));
@@ -2797,6 +2823,8 @@ int x265amd_joblist_results_async(x265amd_ctx *c, x265amd_joblist *L, x265amd_me
     HIPCHK(c, hipSetDevice(c->device));
     if (!L->ran)
         return fail(c, X265AMD_ERR_INVALID, "the job list has not run yet");
+    // (queued on the stream set the list last ran on, right behind that run: the other sets' frames are not held up)
+    StreamSet on(c, L->last_set > 0 ? L->last_set : 0);
     if (int rc = wait_list_done(c, L)) return rc;
     // Page-locked, device-mapped host memory is written by a small kernel behind the run on the main stream (a few
     // microseconds; queueing a DMA copy costs the host about 0.1 ms per call on this platform, and one more stream
