@@ -50,6 +50,19 @@ spans.append((cur_s, cur_e))
 ls, le = max(spans, key=lambda p: p[1] - p[0])
 inside = sum(1 for r in rows if "k_full_hier" in r["Kernel_Name"] and ls <= int(r["Start_Timestamp"]) <= le)
 print("%d k_full_hier dispatches in the trace; longest gap-free stretch: %.3f ms with %d of them -> %.4f ms per frame" % (n_frames, (le - ls) / 1e6, inside, (le - ls) / 1e6 / max(inside, 1)))
+# the time during which at least one k_full_hier dispatch is running (their union), per frame: the pass's rate while
+# several launches share the GPU
+hv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_full_hier" in r["Kernel_Name"] and ls <= int(r["Start_Timestamp"]) <= le)
+u, cs, ce = 0, None, None
+for s, e in hv:
+    if ce is None or s > ce:
+        if ce is not None: u += ce - cs
+        cs, ce = s, e
+    else:
+        ce = max(ce, e)
+u += ce - cs
+px = 3.3966937600e10    # executed pixel-SADs of one 1080p frame (the 8x8 cells of every candidate)
+print("union of the k_full_hier dispatches in that stretch: %.3f ms = %.4f ms per frame -> %.3f of the packed-SAD peak (157.29 T pixel-SAD/s) while they run" % (u / 1e6, u / 1e6 / max(inside, 1), px / (u / 1e9 / max(inside, 1)) / 157.2864e12))
 PY
 } > $R/gpurun_out/${TAG}_union_spans.txt 2>&1
 cat $R/gpurun_out/${TAG}_union_spans.txt
