@@ -408,14 +408,27 @@ __device__ __forceinline__ void hier_item_body(const BatchParams &P, const x265a
         const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + R * yq_lo;
         const int nd = it.win_nd;
         const int64_t first = (int64_t)wy0 * ref.stride + wx0, last = (int64_t)(wy0 + it.win_rows - 1) * ref.stride + wx0 + 4 * (nd - 1);
-        if (first >= lo && last <= hi)
+        const int chunks = (nd + 3) >> 2;               // 16-byte pieces of a window row
+        if (first >= lo && last + 12 <= hi && chunks <= 64)
         {
-            // the whole window lies inside the plane allocation: plain 32-bit offsets
+            // the whole window (and the up to 12 bytes a row's last 16-byte piece reads beyond it) lies inside the plane
+            // allocation: plain 32-bit offsets, 16 bytes per lane, 64 / chunks window rows per load instruction
             const uint8_t *w0 = r0 + first;
             const int stride = ref.stride;
-            for (int r = wv; r < it.win_rows; r += HIER_WAVES)
-                for (int c = lane; c < nd; c += 64)
-                    s_win[r * pitch + c] = ld_u32(w0 + r * stride + 4 * c);
+            const int rpi = 64 / chunks, rr = lane / chunks, ch = lane - rr * chunks;
+            struct __attribute__((packed)) U4 { uint32_t v[4]; };
+            if (rr < rpi)
+#pragma unroll 6
+                for (int r = wv * rpi + rr; r < it.win_rows; r += HIER_WAVES * rpi)
+                {
+                    const XA_GLOBAL U4 *src = (const XA_GLOBAL U4*)(uintptr_t)(w0 + r * stride + 16 * ch);
+                    const uint32_t d0 = src->v[0], d1 = src->v[1], d2 = src->v[2], d3 = src->v[3];
+                    uint32_t *dst = s_win + r * pitch + 4 * ch;
+                    dst[0] = d0;
+                    if (4 * ch + 1 < nd) dst[1] = d1;
+                    if (4 * ch + 2 < nd) dst[2] = d2;
+                    if (4 * ch + 3 < nd) dst[3] = d3;
+                }
         }
         else
         {
