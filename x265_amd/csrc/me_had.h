@@ -418,13 +418,37 @@ __device__ __forceinline__ void had_item_body(const BatchParams &P, const x265am
         const int64_t lo = ref.lo, hi = ref.hi - PPD;
         const int wx0 = B.ctu_x + B.mvx0, wy0 = B.ctu_y + B.mvy0 + y_lo;
         const int nd = it.win_nd;
-        for (int r = wv; r < it.win_rows; r += nwaves)
-            for (int c = lane; c < nd; c += 64)
-            {
-                int64_t a = (int64_t)(wy0 + r) * ref.stride + wx0 + PPD * c;
-                a = a < lo ? lo : (a > hi ? hi : a);
-                s_win[r * pitch + c] = ld_u32(r0 + a * PB);
-            }
+        const int chunks = (nd + 3) >> 2;               // 16-byte pieces of a window row
+        const int64_t first = (int64_t)wy0 * ref.stride + wx0;
+        const int64_t last16 = (int64_t)(wy0 + it.win_rows - 1) * ref.stride + wx0 + 4 * PPD * (chunks - 1);   // the last 16-byte piece
+        if (first >= ref.lo && last16 + 4 * PPD <= ref.hi && chunks <= 64)
+        {
+            // the whole window (with the bytes a row's last 16-byte piece reads beyond it) lies inside the plane allocation:
+            // plain 32-bit offsets, 16 bytes per lane, 64 / chunks window rows per load instruction
+            const uint8_t *w0 = r0 + first * PB;
+            const int stride_b = ref.stride * PB;
+            const int rpi = 64 / chunks, rr = lane / chunks, ch = lane - rr * chunks;
+            struct __attribute__((packed)) U4 { uint32_t v[4]; };
+            if (rr < rpi)
+                for (int r = wv * rpi + rr; r < it.win_rows; r += nwaves * rpi)
+                {
+                    const XA_GLOBAL U4 *src = (const XA_GLOBAL U4*)(uintptr_t)(w0 + r * stride_b + 16 * ch);
+                    const uint32_t d0 = src->v[0], d1 = src->v[1], d2 = src->v[2], d3 = src->v[3];
+                    uint32_t *dst = s_win + r * pitch + 4 * ch;
+                    dst[0] = d0;
+                    if (4 * ch + 1 < nd) dst[1] = d1;
+                    if (4 * ch + 2 < nd) dst[2] = d2;
+                    if (4 * ch + 3 < nd) dst[3] = d3;
+                }
+        }
+        else
+            for (int r = wv; r < it.win_rows; r += nwaves)
+                for (int c = lane; c < nd; c += 64)
+                {
+                    int64_t a = (int64_t)(wy0 + r) * ref.stride + wx0 + PPD * c;
+                    a = a < lo ? lo : (a > hi ? hi : a);
+                    s_win[r * pitch + c] = ld_u32(r0 + a * PB);
+                }
         const uint16_t *cost = P.cost[B.qp];
         if (MASK)
         {
