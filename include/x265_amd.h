@@ -63,7 +63,7 @@ int  x265amd_create(int device, x265amd_ctx **out);
 void x265amd_destroy(x265amd_ctx *ctx);
 /* text of the last error on this context (never NULL) */
 const char *x265amd_last_error(const x265amd_ctx *ctx);
-/* wait for all work queued on the context's stream */
+/* wait for all work queued on the context: every stream set, asynchronous result downloads and plane refills */
 int  x265amd_sync(x265amd_ctx *ctx);
 /* the hipStream_t the context launches on (for callers that time or order against it) */
 void *x265amd_stream(x265amd_ctx *ctx);

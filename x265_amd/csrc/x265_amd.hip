@@ -1643,17 +1643,33 @@ int x265amd_sync(x265amd_ctx *c)
 {
     if (!c)
         return X265AMD_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < x265amd_ctx::N_AUX; i++)
-        HIPCHK(c, hipStreamSynchronize(c->aux[i]));           // runs on the other stream sets
-    if (c->out_stream)
-        HIPCHK(c, hipStreamSynchronize(c->out_stream));       // asynchronous result downloads
-    if (c->up_stream)
-        HIPCHK(c, hipStreamSynchronize(c->up_stream));        // asynchronous plane refills
+    // (the streams are read under the lock - a call that queues on another stream set exchanges them while it holds it -
+    // and waited for outside it, so that other threads can keep queueing)
+    hipStream_t st[1 + x265amd_ctx::N_AUX], out, up;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        st[0] = c->stream;
+        for (int i = 0; i < x265amd_ctx::N_AUX; i++)
+            st[1 + i] = c->aux[i];                            // runs on the other stream sets
+        out = c->out_stream;                                  // asynchronous result downloads
+        up = c->up_stream;                                    // asynchronous plane refills
+    }
+    for (hipStream_t s : st)
+        HIPCHK(c, hipStreamSynchronize(s));
+    if (out)
+        HIPCHK(c, hipStreamSynchronize(out));
+    if (up)
+        HIPCHK(c, hipStreamSynchronize(up));
     return 0;
 }
 
-void *x265amd_stream(x265amd_ctx *c) { return c ? (void*)c->stream : nullptr; }
+void *x265amd_stream(x265amd_ctx *c)
+{
+    if (!c)
+        return nullptr;
+    std::lock_guard<std::mutex> g(c->mu);
+    return (void*)c->stream;
+}
 
 int x265amd_debug_state(x265amd_ctx *c, char *buf, size_t n)
 {
