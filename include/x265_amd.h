@@ -389,12 +389,20 @@ int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes
  * about as long as its longest chain (the smallest PUs).
  *   part_mode[f] (NULL: all 0) = 0: 2Nx2N - every PU is its own CU;
  *                                1: 2NxN - CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 are their upper / lower parts;
- *                                2: Nx2N - CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts.
+ *                                2: Nx2N - CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts;
+ *                                4 / 5: 2NxnU / 2NxnD - CUs of pu_w x pu_h (square, 16, 32 or 64), cut a quarter / three quarters
+ *                                   of the way down: PU rows 2r / 2r + 1 are the upper / lower parts (16x4 + 16x12 ... 64x48 + 64x16);
+ *                                6 / 7: nLx2N / nRx2N - the same across: PU columns 2c / 2c + 1 are the left / right parts
+ *                                   (the numbers are PartSize's, Lib/TLibCommon/TypeDef.h:100-111; 3, NxN, is not an inter mode of
+ *                                   CUs above the smallest and is rejected).
  * CUs are taken in raster order, the two parts of a CU one after the other (the partIdx loop, TEncSearch.cpp:2341).  Against
  * mode 0: clipMv and xSetSearchRange work from the CU's position; the upper part of a 2NxN CU takes candidate A from its
  * below-left neighbour (the lower part of the CU to its left, which the left scan of TComDataCU::fillMvpCand asks first,
  * Lib/TLibCommon/TComDataCU.cpp:2574-2588); its lower part has the upper part above it and nothing coded above-right.
- * Only whole CUs are searched: a 2NxN grid has 2 * (height / (2 pu_h)) PU rows, an Nx2N grid 2 * (width / (2 pu_w)) columns.
+ * The asymmetric parts have the neighbours of the 2NxN / Nx2N parts (the cut moves, the CUs that fillMvpCand's corner positions
+ * fall into do not); their sizes and corners are deriveLeftRightTopIdxGeneral / deriveLeftBottomIdxGeneral's (TComDataCU.cpp:1837-1944).
+ * Only whole CUs are searched: a 2NxN grid has 2 * (height / (2 pu_h)) PU rows, an Nx2N grid 2 * (width / (2 pu_w)) columns, a
+ * 2NxnU / 2NxnD grid 2 * (height / pu_h) rows of width / pu_w PUs, an nLx2N / nRx2N grid height / pu_h rows of 2 * (width / pu_w).
  * out / out_mvp hold the fields one after the other, field f as gw_f x gh_f entries in raster order of its PU grid. */
 int x265amd_field_me_multi(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w,
                            const int *pu_h, const int *part_mode, int merange, int method, int subme, int qp,

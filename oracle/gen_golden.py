@@ -47,6 +47,7 @@ def gen_chain():
         ref.set_bit_depth(8 if bits == 8 else 10)
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_u%d.npz" % bits), **G.run_chain_suite(RefChain(ref), bits))
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_parts_u%d.npz" % bits), **G.run_chain_parts_suite(RefChain(ref), bits))
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_amp_u%d.npz" % bits), **G.run_chain_amp_suite(RefChain(ref), bits))
         print("chain fields, bits", bits)
 
 

@@ -116,7 +116,10 @@ int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, in
 int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int merange,
                      int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
 /* the same for the parts of 2NxN (part_mode 1: CUs of pu_w x 2 pu_h) or Nx2N CUs (2: CUs of 2 pu_w x pu_h), 0 = as above:
- * CUs in raster order, their two parts one after the other; whole CUs only (an odd last PU row / column is left out) */
+ * CUs in raster order, their two parts one after the other; whole CUs only (an odd last PU row / column is left out).
+ * part_mode 4 / 5 / 6 / 7 = the asymmetric partitions 2NxnU / 2NxnD / nLx2N / nRx2N of CUs of pu_w x pu_h (numbered as PartSize,
+ * Lib/TLibCommon/TypeDef.h:100-111): PU rows 2r / 2r + 1 are the upper / lower parts (4, 5: 2 (pic_h / pu_h) PU rows), PU columns
+ * 2c / 2c + 1 the left / right parts (6, 7: 2 (pic_w / pu_w) PUs per row) */
 int64_t meo_field_me_parts(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
                            int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
 

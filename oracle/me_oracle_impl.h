@@ -1124,28 +1124,53 @@ static inline int SUF(clipi)(int v, int lo, int hi)
  * searched one after the other (the partIdx loop, :2341).  clipMv / xSetSearchRange take the CU's position.  Where the
  * neighbour positions of TComDataCU::fillMvpCand (TComDataCU.cpp:2553-2633) fall: the upper part of a 2NxN CU has the
  * lower part of the CU to its left below-left of it, coded already, and the left scan asks below-left first (:2574-2588),
- * so A is that PU's MV; the lower part has the upper part of its own CU above it and nothing coded above-right. */
+ * so A is that PU's MV; the lower part has the upper part of its own CU above it and nothing coded above-right.
+ * part_mode 4..7 (the asymmetric partitions, numbered as PartSize, Lib/TLibCommon/TypeDef.h:100-111): pu_w x pu_h is the CU;
+ * 4 (2NxnU) / 5 (2NxnD) cut it into an upper and a lower part a quarter / three quarters of the way down, 6 (nLx2N) / 7
+ * (nRx2N) into a left and a right part; PU sizes and corner positions follow deriveLeftRightTopIdxGeneral /
+ * deriveLeftBottomIdxGeneral (TComDataCU.cpp:1837-1944), and the neighbours are those of mode 1 / mode 2 (the cut moves, the
+ * CUs the corner positions fall into do not).  PU rows 2r / 2r + 1 (columns 2c / 2c + 1) are the two parts, as there. */
 static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
                              int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
 {
     SUF(state) *st = (SUF(state)*)malloc(sizeof(SUF(state)));
     int64_t evals = 0;
     const int max_cu = 64;
+    /* modes 4..7 (AMP): pu_w x pu_h is the CU, cut at a quarter (4: 2NxnU, 6: nLx2N) or three quarters (5: 2NxnD, 7: nRx2N) */
+    const int horiz = part_mode == 1 || part_mode == 4 || part_mode == 5;    /* upper / lower parts */
+    const int vert = part_mode == 2 || part_mode == 6 || part_mode == 7;     /* left / right parts */
+    const int amp = part_mode >= 4;
     int gw = pic_w / pu_w, gh = pic_h / pu_h;
     if (part_mode == 1) gh &= ~1;
     if (part_mode == 2) gw &= ~1;
-    const int parts = part_mode == 1 ? 2 : 1;
+    if (amp && horiz) gh *= 2;
+    if (amp && vert) gw *= 2;
+    const int cut_h = part_mode == 4 ? pu_h >> 2 : pu_h - (pu_h >> 2), cut_w = part_mode == 6 ? pu_w >> 2 : pu_w - (pu_w >> 2);
+    const int parts = horiz ? 2 : 1;
     for (int row = 0; row < gh / parts; row++)
     {
         for (int gx = 0; gx < gw; gx++)
           for (int part = 0; part < parts; part++)
           {
             const int gy = row * parts + part, lower = part == 1;
-            const int xy = gx + gy * gw, px = gx * pu_w, py = gy * pu_h;
-            const int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
+            const int xy = gx + gy * gw;
+            int px = gx * pu_w, py = gy * pu_h, bw = pu_w, bh = pu_h;
+            int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
+            if (amp && horiz)
+            {
+                cuy = row * pu_h;
+                py = cuy + (lower ? cut_h : 0);
+                bh = lower ? pu_h - cut_h : cut_h;
+            }
+            if (amp && vert)
+            {
+                cux = (gx >> 1) * pu_w;
+                px = cux + ((gx & 1) ? cut_w : 0);
+                bw = (gx & 1) ? pu_w - cut_w : cut_w;
+            }
             const int have_l = gx > 0, have_a = gy > 0, have_ar = !lower && gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
             /* candidate A: the left neighbour; for the upper part of a 2NxN CU the below-left one */
-            const int xa = part_mode == 1 && !lower ? xy + gw - 1 : xy - 1;
+            const int xa = horiz && !lower ? xy + gw - 1 : xy - 1;
             int c[2][2] = { { 0, 0 }, { 0, 0 } };
             int bx = 0, by = 0, have_b = 0;
             if (have_ar)      { bx = out[xy - gw + 1].mvx; by = out[xy - gw + 1].mvy; have_b = 1; }
@@ -1165,7 +1190,7 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             }
             const int xmax = (pic_w + 8 - cux - 1) << 2, xmin = (-max_cu - 8 - cux + 1) << 2;
             const int ymax = (pic_h + 8 - cuy - 1) << 2, ymin = (-max_cu - 8 - cuy + 1) << 2;
-            SUF(bind)(st, enc, ref, px, py, pu_w, pu_h, qp);
+            SUF(bind)(st, enc, ref, px, py, bw, bh, qp);
             int mvpx = c[0][0], mvpy = c[0][1];
             if (c[1][0] != c[0][0] || c[1][1] != c[0][1])
             {
@@ -1179,7 +1204,7 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             evals += st->evals;
             meo_job j;
             memset(&j, 0, sizeof(j));
-            j.pu_x = px; j.pu_y = py; j.w = (int16_t)pu_w; j.h = (int16_t)pu_h;
+            j.pu_x = px; j.pu_y = py; j.w = (int16_t)bw; j.h = (int16_t)bh;
             const int cpx = SUF(clipi)(mvpx, xmin, xmax), cpy = SUF(clipi)(mvpy, ymin, ymax);
             j.mvmin_x = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpx - (merange << 2)), xmin, xmax) >> 2);
             j.mvmin_y = (int16_t)((int16_t)SUF(clipi)((int16_t)(cpy - (merange << 2)), ymin, ymax) >> 2);
@@ -1191,7 +1216,7 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             if (have_l)  { j.mvc[0][0] = out[xy - 1].mvx;      j.mvc[0][1] = out[xy - 1].mvy; }
             if (have_a)  { j.mvc[1][0] = out[xy - gw].mvx;     j.mvc[1][1] = out[xy - gw].mvy; }
             if (have_ar) { j.mvc[2][0] = out[xy - gw + 1].mvx; j.mvc[2][1] = out[xy - gw + 1].mvy; }
-            SUF(bind)(st, enc, ref, px, py, pu_w, pu_h, qp);
+            SUF(bind)(st, enc, ref, px, py, bw, bh, qp);
             out[xy].cost = SUF(search)(st, &j, &out[xy].mvx, &out[xy].mvy);
             evals += st->evals;
             if (out_mvp)

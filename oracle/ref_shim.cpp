@@ -392,7 +392,9 @@ static inline void shim_clip(MV &mv, int picw, int pich, int px, int py)
  * Nx2N CUs (2 puw x puh), PU columns 2c / 2c + 1.  CUs in raster order, parts one after the other (the partIdx loop, :2341);
  * clipMv / xSetSearchRange from the CU's position; the upper part of a 2NxN CU takes candidate A from below-left (the lower
  * part of the CU to the left: TComDataCU::fillMvpCand asks below-left before left, TComDataCU.cpp:2574-2588), the lower part
- * has the upper part above it and nothing coded above-right. */
+ * has the upper part above it and nothing coded above-right.  4 / 5 / 6 / 7: the parts of 2NxnU / 2NxnD / nLx2N / nRx2N CUs of
+ * puw x puh (sizes and corner positions: deriveLeftRightTopIdxGeneral / deriveLeftBottomIdxGeneral, TComDataCU.cpp:1837-1944);
+ * their neighbours are those of partMode 1 / 2. */
 void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh, int partMode,
                         int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
 {
@@ -405,10 +407,16 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
     r->planes.lumaStride = (int)stride;
     r->planes.isLowres = false;
     r->planes.lowresPlane[0] = ref;
+    // partMode 4..7: puw x puh is the CU of an asymmetric partition (PartSize numbering, TypeDef.h:100-111)
+    const bool horiz = partMode == 1 || partMode == 4 || partMode == 5, vert = partMode == 2 || partMode == 6 || partMode == 7;
+    const bool amp = partMode >= 4;
     int gw = picw / puw, gh = pich / puh;
     if (partMode == 1) gh &= ~1;
     if (partMode == 2) gw &= ~1;
-    const int parts = partMode == 1 ? 2 : 1;
+    if (amp && horiz) gh *= 2;
+    if (amp && vert) gw *= 2;
+    const int cutH = partMode == 4 ? puh >> 2 : puh - (puh >> 2), cutW = partMode == 6 ? puw >> 2 : puw - (puw >> 2);
+    const int parts = horiz ? 2 : 1;
     MV *mvs = new MV[gw * gh];
     ALIGN_VAR_32(pixel, pred[64 * 64]);
     short *tmp = new short[64 * (64 + 7)];
@@ -419,10 +427,23 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
           {
             const int gy = row * parts + part;
             const bool lower = part == 1;
-            const int xy = gx + gy * gw, px = gx * puw, py = gy * puh;
-            const int cux = partMode == 2 ? (gx & ~1) * puw : px, cuy = partMode == 1 ? py - part * puh : py;
+            const int xy = gx + gy * gw;
+            int px = gx * puw, py = gy * puh, bw = puw, bh = puh;
+            int cux = partMode == 2 ? (gx & ~1) * puw : px, cuy = partMode == 1 ? py - part * puh : py;
+            if (amp && horiz)
+            {
+                cuy = row * puh;
+                py = cuy + (lower ? cutH : 0);
+                bh = lower ? puh - cutH : cutH;
+            }
+            if (amp && vert)
+            {
+                cux = (gx >> 1) * puw;
+                px = cux + ((gx & 1) ? cutW : 0);
+                bw = (gx & 1) ? puw - cutW : cutW;
+            }
             const int puOffset = px + py * (int)stride;
-            r->me.setSourcePU(puOffset, puw, puh);
+            r->me.setSourcePU(puOffset, bw, bh);
             const bool haveL = gx > 0, haveA = gy > 0, haveAR = !lower && gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
             MV mvPredictors[3];                        // left, above, above-right (zero when absent)
             if (haveL)  mvPredictors[0] = mvs[xy - 1];
@@ -433,7 +454,7 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
             if (haveAR) b = mvs[xy - gw + 1]; else if (haveA) b = mvs[xy - gw]; else if (haveAL) b = mvs[xy - gw - 1];
             if (haveL)
             {
-                cand[0] = (partMode == 1 && !lower) ? mvs[xy + gw - 1] : mvs[xy - 1];
+                cand[0] = (horiz && !lower) ? mvs[xy + gw - 1] : mvs[xy - 1];
                 if (haveB && b != cand[0]) cand[1] = b;
             }
             else if (haveB)
@@ -451,19 +472,19 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
                     unsigned cost;
                     if (!(xFrac | yFrac))
                     {
-                        primitives.blockcpy_pp(puw, puh, pred, 64, src, stride);
+                        primitives.blockcpy_pp(bw, bh, pred, 64, src, stride);
                         cost = r->me.bufSAD(pred, 64);
                     }
                     else
                     {
                         if (!yFrac)
-                            primitives.ipfilter_pp[FILTER_H_P_P_8](src, stride, pred, 64, puw, puh, g_lumaFilter[xFrac]);
+                            primitives.ipfilter_pp[FILTER_H_P_P_8](src, stride, pred, 64, bw, bh, g_lumaFilter[xFrac]);
                         else if (!xFrac)
-                            primitives.ipfilter_pp[FILTER_V_P_P_8](src, stride, pred, 64, puw, puh, g_lumaFilter[yFrac]);
+                            primitives.ipfilter_pp[FILTER_V_P_P_8](src, stride, pred, 64, bw, bh, g_lumaFilter[yFrac]);
                         else
                         {
-                            primitives.ipfilter_ps[FILTER_H_P_S_8](src - 3 * stride, stride, tmp, puw, puw, puh + 7, g_lumaFilter[xFrac]);
-                            primitives.ipfilter_sp[FILTER_V_S_P_8](tmp + 3 * puw, puw, pred, 64, puw, puh, g_lumaFilter[yFrac]);
+                            primitives.ipfilter_ps[FILTER_H_P_S_8](src - 3 * stride, stride, tmp, bw, bw, bh + 7, g_lumaFilter[xFrac]);
+                            primitives.ipfilter_sp[FILTER_V_S_P_8](tmp + 3 * bw, bw, pred, 64, bw, bh, g_lumaFilter[yFrac]);
                         }
                         cost = r->me.bufSAD(pred, 64);
                     }

@@ -189,13 +189,14 @@ int main(int argc, char **argv)
             printf("chainstats %u %u %d\n", field.hits(), field.misses(), gw * gh);
             me.attachField(NULL);
         }
-        // (8) fields of several PU sizes and partition modes from ONE device call: the 2Nx2N fields of the 16x16 and 32x32 CUs and
-        //     the 2NxN / Nx2N fields of the 16x16 CUs.  For each an "encoder" that codes every CU in that mode walks the CUs in
+        // (8) fields of several PU sizes and partition modes from ONE device call: the 2Nx2N fields of the 16x16 and 32x32 CUs, the
+        //     2NxN / Nx2N fields of the 16x16 CUs, the 2NxnU field of the 32x32 and the nRx2N field of the 16x16 CUs.  For each an "encoder" that codes every CU in that mode walks the CUs in
         //     raster order, part by part, derives the predictors from its own decisions by the rules of the partition mode and
         //     calls motionEstimate at the unchanged call site.  One part per field is "coded intra".
         {
             typedef x265amd::MotionField::Shape Shape;
-            const std::vector<Shape> shapes = { Shape{ 16, 16, 0 }, Shape{ 32, 32, 0 }, Shape{ 16, 8, 1 }, Shape{ 8, 16, 2 } };
+            const std::vector<Shape> shapes = { Shape{ 16, 16, 0 }, Shape{ 32, 32, 0 }, Shape{ 16, 8, 1 }, Shape{ 8, 16, 2 },
+                                                Shape{ 32, 32, 4 }, Shape{ 16, 16, 7 } };
             const int merange = 24;
             x265amd::MotionField field(ctx);
             me.setSearchMethod(1);
@@ -209,7 +210,8 @@ int main(int argc, char **argv)
                 const Shape &sh = shapes[f];
                 int gw, gh;
                 x265amd::MotionField::shapeGrid(pe, sh, gw, gh);
-                const int parts = sh.part_mode == 1 ? 2 : 1;
+                const bool twoRows = x265amd::MotionField::upperLower(sh.part_mode);
+                const int parts = twoRows ? 2 : 1;
                 std::vector<x265amd::MV> dec(gw * gh);
                 for (int row = 0; row < gh / parts; row++)
                     for (int gx = 0; gx < gw; gx++)
@@ -217,9 +219,9 @@ int main(int argc, char **argv)
                         {
                             const int gy = row * parts + part, xy = gx + gy * gw;
                             const bool lower = part == 1;
-                            const int px = gx * sh.pu_w, py = gy * sh.pu_h;
-                            const int cuX = sh.part_mode == 2 ? (gx & ~1) * sh.pu_w : px, cuY = lower ? py - sh.pu_h : py;
-                            me.setSourcePUxy(px, py, sh.pu_w, sh.pu_h);
+                            const x265amd::MotionField::PuRect pu = x265amd::MotionField::shapePu(sh, gx, gy);
+                            const int px = pu.x, py = pu.y, cuX = pu.cuX, cuY = pu.cuY;
+                            me.setSourcePUxy(px, py, pu.w, pu.h);
                             const bool haveL = gx > 0, haveA = gy > 0, haveAR = !lower && gy > 0 && gx + 1 < gw, haveAL = gy > 0 && gx > 0;
                             x265amd::MV pred[3], cand[2], b;
                             if (haveL) pred[0] = dec[xy - 1];
@@ -227,8 +229,8 @@ int main(int argc, char **argv)
                             if (haveAR) pred[2] = dec[xy - gw + 1];
                             const bool haveB = haveAR || haveA || haveAL;
                             if (haveAR) b = dec[xy - gw + 1]; else if (haveA) b = dec[xy - gw]; else if (haveAL) b = dec[xy - gw - 1];
-                            // (upper part of a 2NxN CU: the left scan finds the below-left neighbour first)
-                            const x265amd::MV a = haveL ? ((sh.part_mode == 1 && !lower) ? dec[xy + gw - 1] : dec[xy - 1]) : x265amd::MV();
+                            // (upper part of a 2NxN / 2NxnU / 2NxnD CU: the left scan finds the below-left neighbour first)
+                            const x265amd::MV a = haveL ? ((twoRows && !lower) ? dec[xy + gw - 1] : dec[xy - 1]) : x265amd::MV();
                             if (haveL) { cand[0] = a; if (haveB && b != cand[0]) cand[1] = b; }
                             else if (haveB) cand[0] = b;
                             x265amd::MV mvp = cand[0];
@@ -245,7 +247,7 @@ int main(int argc, char **argv)
                             const bool intra = xy == 21;
                             dec[xy] = intra ? x265amd::MV(0, 0) : out;
                             total++;
-                            printf("mchain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", sh.pu_w, sh.pu_h, sh.part_mode, gx, gy,
+                            printf("mchain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", pu.w, pu.h, sh.part_mode, px, py,
                                    mvp.x, mvp.y, lo.x, lo.y, hi.x, hi.y, pred[0].x, pred[0].y, pred[1].x, pred[1].y, pred[2].x, pred[2].y,
                                    out.x, out.y, cost, intra ? 1 : 0);
                         }

@@ -74,8 +74,16 @@ def main():
             cus += 2 * g.cu_w * g.cu_h
             what = "lookahead %4dx%-4d" % (w, h)
         else:
-            # ---- predictor-chained field of one PU size
-            pw, ph = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)][int(rng.integers(0, 7))]
+            # ---- predictor-chained field of one PU size and partition mode (0 2Nx2N, 1 2NxN, 2 Nx2N, 4..7 the asymmetric ones)
+            pm = int(rng.choice([0, 0, 1, 2, 4, 5, 6, 7]))
+            if pm >= 4:
+                pw = ph = int(rng.choice([16, 32, 64]))
+            elif pm:
+                pw, ph = [(16, 8), (32, 16), (64, 32), (8, 4), (16, 16), (8, 8)][int(rng.integers(0, 6))]
+                if pm == 2:
+                    pw, ph = ph, pw
+            else:
+                pw, ph = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)][int(rng.integers(0, 7))]
             w, h = 8 * int(rng.integers(max(2, pw // 8 * 2), 60)), 8 * int(rng.integers(max(2, ph // 8 * 2), 36))
             fr = make_frames(rng, w, h, depth, kind)
             method, subme = int(rng.integers(0, 5)), int(rng.integers(0, 8))
@@ -83,17 +91,19 @@ def main():
             if method == 4:
                 merange = 8
             ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
-            got, got_mvp = eng.field_me(ids[1], ids[0], pw, ph, merange, method, subme, qp)
-            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth)
+            if method == 2 and pw * ph == 16:       # (UMH has no 4x4)
+                method = 1
+            got, got_mvp = eng.field_me_multi([ids[1]], [ids[0]], [pw], [ph], [pm], merange, method, subme, qp)[0]
+            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth, part_mode=pm)
             if not (np.array_equal(got, exp) and np.array_equal(got_mvp, exp_mvp)):
-                print("MISMATCH field %dx%d PU %dx%d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
-                      % (w, h, pw, ph, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
+                print("MISMATCH field %dx%d PU %dx%d mode %d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
+                      % (w, h, pw, ph, pm, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
                 sys.exit(1)
             for p in ids:
                 eng.release_plane(p)
             n_field += 1
             pus += got.size
-            what = "field %4dx%-4d PU %2dx%-2d" % (w, h, pw, ph)
+            what = "field %4dx%-4d PU %2dx%-2d mode %d" % (w, h, pw, ph, pm)
         if (n_look + n_field) % 20 == 0:
             print("case %d ok: %s %2d-bit depth %2d %-6s (%d s)" % (n_look + n_field, what, bits, depth, kind, time.time() - t0), flush=True)
     print("chained-path campaign: %d lookahead cases (%d CU searches) and %d chained fields (%d PU searches), all bit-exact against "

@@ -279,3 +279,24 @@ def run_chain_parts_suite(impl, bits: int) -> dict:
         out["res%d" % k] = np.ascontiguousarray(res)
         out["mvp%d" % k] = np.ascontiguousarray(mvp)
     return out
+
+
+# the same for the asymmetric partitions of a CU of cu x cu (part_mode 4 = 2NxnU, 5 = 2NxnD, 6 = nLx2N, 7 = nRx2N, numbered as
+# PartSize, Lib/TLibCommon/TypeDef.h:100-111): (cu, part_mode, merange, method, subme, qp, content); every one of the twelve
+# asymmetric PU shapes (16x4 .. 48x64) appears, under every method
+CHAIN_AMP_CASES = ((16, 4, 24, J.HEX, 5, 30, "motion"), (16, 5, 16, J.DIA, 2, 28, "motion"), (16, 6, 20, J.STAR, 3, 33, "motion"),
+                   (16, 7, 12, J.UMH, 1, 26, "noise"), (32, 4, 24, J.UMH, 4, 31, "motion"), (32, 5, 20, J.STAR, 6, 25, "noise"),
+                   (32, 6, 16, J.DIA, 3, 36, "motion"), (32, 7, 16, J.HEX, 7, 35, "noise"), (64, 4, 16, J.STAR, 2, 32, "motion"),
+                   (64, 5, 32, J.HEX, 3, 29, "motion"), (64, 6, 8, J.FULL, 0, 30, "motion"), (64, 7, 24, J.UMH, 5, 27, "motion"),
+                   (16, 4, 5, J.FULL, 2, 34, "noise"))
+
+
+def run_chain_amp_suite(impl, bits: int) -> dict:
+    """impl.field_run(enc, ref, cu, cu, merange, method, subme, qp, part_mode=m) -> (results[gh, gw], mvp[gh, gw, 2])"""
+    out = {}
+    for k, (cu, pm, mr, method, subme, qp, kind) in enumerate(CHAIN_AMP_CASES):
+        fr = chain_frames(bits, kind)
+        res, mvp = impl.field_run(fr[1], fr[0], cu, cu, mr, method, subme, qp, part_mode=pm)
+        out["res%d" % k] = np.ascontiguousarray(res)
+        out["mvp%d" % k] = np.ascontiguousarray(mvp)
+    return out

@@ -27,6 +27,21 @@ from x265_amd.jobs import JOB_DTYPE, RESULT_DTYPE  # noqa: E402
 from x265_amd.synth import MARGIN  # noqa: E402
 
 
+
+def field_grid(pic_w, pic_h, pu_w, pu_h, part_mode=0):
+    """(PUs per row, PU rows) of a chained field: whole CUs only.  part_mode 1 / 2: CUs of pu_w x 2 pu_h / 2 pu_w x pu_h;
+    4, 5 / 6, 7 (asymmetric partitions): CUs of pu_w x pu_h with two PU rows / two PU columns each"""
+    gw, gh = pic_w // pu_w, pic_h // pu_h
+    if part_mode == 1:
+        gh &= ~1
+    if part_mode == 2:
+        gw &= ~1
+    if part_mode in (4, 5):
+        gh *= 2
+    if part_mode in (6, 7):
+        gw *= 2
+    return gw, gh
+
 class MeoPlane(C.Structure):
     _fields_ = [("pix", C.c_void_p), ("stride", C.c_ssize_t), ("bytes_per_px", C.c_int),
                 ("bit_depth", C.c_int), ("lowres", C.c_void_p * 4)]
@@ -132,12 +147,11 @@ class Oracle:
     def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN,
                  part_mode: int = 0):
         """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain
-        (part_mode 1 / 2: the parts of 2NxN / Nx2N CUs)"""
+        (part_mode 1 / 2: the parts of 2NxN / Nx2N CUs, 4..7: of 2NxnU / 2NxnD / nLx2N / nRx2N CUs of pu_w x pu_h)"""
         enc = self.make_plane(enc_padded, bit_depth, margin)
         ref = self.make_plane(ref_padded, bit_depth, margin)
         pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
-        gw, gh = pw // pu_w, ph // pu_h
-        gw, gh = (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
+        gw, gh = field_grid(pw, ph, pu_w, pu_h, part_mode)
         out = np.zeros((gh, gw), dtype=RESULT_DTYPE)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)
         self.lib.meo_field_me_parts.restype = C.c_int64
@@ -266,8 +280,7 @@ class Reference:
         """(results[gh, gw], mvp[gh, gw, 2]): the reference's MotionEstimate driven over a PU grid with
         predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me_parts)"""
         pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
-        gw, gh = pw // pu_w, ph // pu_h
-        gw, gh = (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
+        gw, gh = field_grid(pw, ph, pu_w, pu_h, part_mode)
         mv = np.zeros((gh * gw, 2), dtype=np.int16)
         cost = np.zeros(gh * gw, dtype=np.int32)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)

@@ -119,11 +119,12 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
     # (8) fields of several PU sizes and partition modes from one device call, each behind its own walk of the CUs
     rows = [l for l in lines if l[0] == "mchain"]
     n_exp = (W // 16) * (H // 16) + (W // 32) * (H // 32) + 2 * (W // 16) * (H // 16) + 2 * (W // 16) * (H // 16)
+    n_exp += 2 * (W // 32) * (H // 32) + 2 * (W // 16) * (H // 16)          # the 2NxnU field of 32x32, the nRx2N field of 16x16
     assert len(rows) == n_exp
     parts = []
     for l in rows:
         v = [int(t) for t in l[1:]]
-        jb = J.make_jobs(W, H, [v[3] * v[0]], [v[4] * v[1]], v[0], v[1], method=J.HEX, subme=3, merange=24, qp=28, qmvp=(v[5], v[6]),
+        jb = J.make_jobs(W, H, [v[3]], [v[4]], v[0], v[1], method=J.HEX, subme=3, merange=24, qp=28, qmvp=(v[5], v[6]),
                          mvc=[[v[11], v[12]], [v[13], v[14]], [v[15], v[16]]])
         jb["mvmin_x"], jb["mvmin_y"], jb["mvmax_x"], jb["mvmax_y"] = v[7], v[8], v[9], v[10]
         parts.append(jb)

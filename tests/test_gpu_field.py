@@ -57,6 +57,40 @@ def test_predictor_chain_fields_of_cu_parts_match_reference_vectors(eng, bits):
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
 
 
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_of_asymmetric_parts_match_reference_vectors(eng, bits):
+    """the parts of 2NxnU / 2NxnD / nLx2N / nRx2N CUs (part modes 4..7) against the fixtures made by the compiled reference under
+    the same driver: all twelve asymmetric PU shapes, 16x4 .. 48x64, all five methods"""
+    gold = np.load(os.path.join(G.GOLDEN_DIR, "chain_amp_u%d.npz" % bits), allow_pickle=False)
+    got = G.run_chain_amp_suite(GpuChain(eng, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+def test_1080p_asymmetric_fields_beside_the_square_ones_in_one_call(eng, oracle):
+    """one call, one 1080p frame: the four asymmetric fields of the 32x32 CUs, two of the 16x16 and two of the 64x64 CUs beside
+    the 2Nx2N field of 32x32; every field and the evaluation total equal the oracle's"""
+    W, H = 1920, 1080
+    fr = synth.make_sequence(W, H, 2, seed=93)
+    ids = [eng.upload_plane(f) for f in fr]
+    shapes = [(32, 32, 0), (32, 32, 4), (32, 32, 5), (32, 32, 6), (32, 32, 7), (16, 16, 4), (16, 16, 7), (64, 64, 5), (64, 64, 6)]
+    n = len(shapes)
+    eng.eval_count(reset=True)
+    got = eng.field_me_multi([ids[1]] * n, [ids[0]] * n, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes],
+                             32, J.HEX, 3, 30)
+    total = 0
+    for (pw, ph, pm), (res, mvp) in zip(shapes, got):
+        exp, exp_mvp, evals = oracle.field_me(fr[1], fr[0], pw, ph, 32, J.HEX, 3, 30, part_mode=pm)
+        assert res.shape == exp.shape, (pw, ph, pm)
+        assert np.array_equal(res, exp), ((pw, ph, pm), np.argwhere(res != exp)[:5])
+        assert np.array_equal(mvp, exp_mvp), (pw, ph, pm)
+        total += evals
+    assert eng.eval_count() == total
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_1080p_fields_of_every_depth_and_part_mode_in_one_call(eng, oracle):
     """One call, one 1080p frame, a field per quadtree depth (64x64 .. 8x8) plus the 2NxN and Nx2N fields of the 16x16 and
     32x32 CUs: every field equals the oracle's, the evaluation counts add up, and the call takes about as long as its
@@ -141,6 +175,10 @@ def test_field_rejects_bad_arguments(eng):
     ids = [eng.upload_plane(f) for f in fr]
     with pytest.raises(X265AmdError):
         eng.field_me(ids[0], ids[1], 20, 16, 16, J.HEX, 1, 30)
+    # part modes: NxN (3) and numbers past nRx2N; asymmetric parts of an 8x8 or a non-square CU
+    for pw, ph, pm in ((16, 16, 3), (16, 16, 8), (8, 8, 4), (32, 16, 6), (64, 64, 1)):
+        with pytest.raises(X265AmdError):
+            eng.field_me_multi([ids[0]], [ids[1]], [pw], [ph], [pm], 16, J.HEX, 1, 30)
     small = synth.make_sequence(128, 64, 1, seed=3)[0][16:-16, 16:-16].copy()       # margins of 64 < 78
     sid = eng.upload_plane(small, margin=64)
     with pytest.raises(X265AmdError, match="-5"):

@@ -128,3 +128,14 @@ def test_predictor_chain_fields_of_cu_parts_match_reference_vectors(oracle, bits
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
 
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_of_asymmetric_parts_match_reference_vectors(oracle, bits):
+    """the same for the two parts of 2NxnU / 2NxnD / nLx2N / nRx2N CUs of 16, 32 and 64 pixels: all twelve asymmetric PU
+    shapes, PU sizes and positions from the quarter / three-quarter cut, neighbours as for 2NxN / Nx2N"""
+    gold = _load("chain_amp_u%d.npz" % bits)
+    got = G.run_chain_amp_suite(OracleChain(oracle, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+

@@ -317,8 +317,13 @@ class Engine:
 
     @staticmethod
     def field_grid(w: int, h: int, pu_w: int, pu_h: int, part_mode: int = 0):
-        """(PUs per row, PU rows) of a field: whole CUs only (part_mode 1 = 2NxN: CUs of pu_w x 2 pu_h, 2 = Nx2N: 2 pu_w x pu_h)"""
+        """(PUs per row, PU rows) of a field: whole CUs only (part_mode 1 = 2NxN: CUs of pu_w x 2 pu_h, 2 = Nx2N: 2 pu_w x pu_h;
+        4 / 5 = 2NxnU / 2NxnD and 6 / 7 = nLx2N / nRx2N: CUs of pu_w x pu_h, two PU rows / two PU columns each)"""
         gw, gh = w // pu_w, h // pu_h
+        if part_mode in (4, 5):
+            return gw, 2 * gh
+        if part_mode in (6, 7):
+            return 2 * gw, gh
         return (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
 
     def field_me_multi(self, enc_planes, ref_planes, pu_w, pu_h, part_mode, merange: int, method: int, subme: int, qp: int,

@@ -45,7 +45,12 @@ namespace xa {
 //     yet - B = the upper part's MV, and the third start candidate is zero;
 //   * Nx2N: the neighbours are those of the uniform grid (the left part's left neighbour is the right part of the CU to
 //     the left, the right part's is the left part of its own CU).
-// With part_mode 1 one workgroup owns a CU row (two PU rows, walked upper part, lower part, next CU) and `gh` counts CU rows.
+// part_mode 4 / 5 / 6 / 7 (2NxnU / 2NxnD / nLx2N / nRx2N, numbered as PartSize, Lib/TLibCommon/TypeDef.h:100-111): pu_w x pu_h is the
+// CU, cut a quarter (4, 6) or three quarters (5, 7) of the way down / across; PU sizes and corner positions are those of
+// deriveLeftRightTopIdxGeneral / deriveLeftBottomIdxGeneral (TComDataCU.cpp:1837-1944).  The cut moves, the CUs that the corner
+// positions fall into do not: the neighbours of the two parts are those of mode 1 (4, 5) / mode 2 (6, 7).
+// With upper / lower parts (modes 1, 4, 5) one workgroup owns a CU row (two PU rows, walked upper part, lower part, next CU) and
+// `gh` counts CU rows.
 template <class L>
 __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
                                                  int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
@@ -55,7 +60,10 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
     __shared__ __align__(16) L lds;
     // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU (CU) rows of field f, top row first
     const int field = (int)blockIdx.x / gh, row = (int)blockIdx.x - field * gh;
-    const int parts = part_mode == 1 ? 2 : 1;                            // PU rows per workgroup
+    const bool amp = part_mode >= 4;
+    const bool horiz = part_mode == 1 || part_mode == 4 || part_mode == 5, vert = part_mode == 2 || part_mode == 6 || part_mode == 7;
+    const int parts = horiz ? 2 : 1;                                     // PU rows per workgroup
+    const int cut_h = part_mode == 4 ? pu_h >> 2 : pu_h - (pu_h >> 2), cut_w = part_mode == 6 ? pu_w >> 2 : pu_w - (pu_w >> 2);
     out += (size_t)field * gw * gh * parts;
     out_mvp += (size_t)field * gw * gh * parts;
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
@@ -78,12 +86,24 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
       for (int part = 0; part < parts; part++)
       {
         const int gy = row * parts + part;
-        const int px = gx * pu_w, py = gy * pu_h;
-        const int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
         const bool lower = part == 1;
+        int px = gx * pu_w, py = gy * pu_h, bw = pu_w, bh = pu_h;
+        int cux = part_mode == 2 ? (gx & ~1) * pu_w : px, cuy = part_mode == 1 ? py - part * pu_h : py;
+        if (amp && horiz)
+        {
+            cuy = row * pu_h;
+            py = cuy + (lower ? cut_h : 0);
+            bh = lower ? pu_h - cut_h : cut_h;
+        }
+        if (amp && vert)
+        {
+            cux = (gx >> 1) * pu_w;
+            px = cux + ((gx & 1) ? cut_w : 0);
+            bw = (gx & 1) ? pu_w - cut_w : cut_w;
+        }
         const bool have_l = gx > 0, have_a = gy > 0, have_ar = !lower && gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
         // (the PU is cached while the row above may still be busy)
-        W.bind(lds, enc, ref, px, py, px, py, pu_w, pu_h, cost, flags, true);
+        W.bind(lds, enc, ref, px, py, px, py, bw, bh, cost, flags, true);
         int w_al = 0, w_a = 0, w_ar = 0;
         if (lower)
             w_a = cur_top;                                              // (B = above exists: above-left is never asked for)
@@ -132,7 +152,7 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
             }
         }
         JobRegs j;
-        j.pu_x = px; j.pu_y = py; j.w = pu_w; j.h = pu_h;
+        j.pu_x = px; j.pu_y = py; j.w = bw; j.h = bh;
         // xSetSearchRange
         const int cpx = clipq(mvpx, xmin, xmax), cpy = clipq(mvpy, ymin, ymax);
         j.mvmin_x = XA_S16(clipq(XA_S16(cpx - (merange << 2)), xmin, xmax)) >> 2;

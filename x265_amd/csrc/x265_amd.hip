@@ -2138,14 +2138,18 @@ void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_fields, int gh,
 #undef XA_FIELD
 }
 
-// PU grid of a field: PUs per row, PU rows (whole CUs only: an odd last PU row / column of a 2NxN / Nx2N grid is left out)
+// PU grid of a field: PUs per row, PU rows (whole CUs only: an odd last PU row / column of a 2NxN / Nx2N grid is left out; the
+// asymmetric modes 4..7 take the CU's size and have two PU rows (4, 5) or two PU columns (6, 7) per CU)
 bool field_grid(int pic_w, int pic_h, int pu_w, int pu_h, int part_mode, int &gw, int &gh)
 {
     gw = pic_w / pu_w; gh = pic_h / pu_h;
     if (part_mode == 1) gh &= ~1;
     if (part_mode == 2) gw &= ~1;
+    if (part_mode == 4 || part_mode == 5) gh *= 2;
+    if (part_mode == 6 || part_mode == 7) gw *= 2;
     return gw >= 1 && gh >= 1;
 }
+bool field_two_rows(int part_mode) { return part_mode == 1 || part_mode == 4 || part_mode == 5; }   // upper / lower parts
 } // namespace
 } // extern "C++"
 
@@ -2163,8 +2167,9 @@ int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     for (int f = 0; f < n_fields; f++)
     {
         const int pm = part_mode ? part_mode[f] : 0;
-        if (!valid_dim(pu_w[f]) || !valid_dim(pu_h[f]) || pm < 0 || pm > 2 || (method == X265AMD_UMH && pu_w[f] == 4 && pu_h[f] == 4) ||
-            (pm == 1 && 2 * pu_h[f] > 64) || (pm == 2 && 2 * pu_w[f] > 64))
+        if (!valid_dim(pu_w[f]) || !valid_dim(pu_h[f]) || pm < 0 || pm > 7 || pm == 3 || (method == X265AMD_UMH && pu_w[f] == 4 && pu_h[f] == 4) ||
+            (pm == 1 && 2 * pu_h[f] > 64) || (pm == 2 && 2 * pu_w[f] > 64) ||
+            (pm >= 4 && (pu_w[f] != pu_h[f] || (pu_w[f] != 16 && pu_w[f] != 32 && pu_w[f] != 64))))
             return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
         const int refs[1] = { ref_planes[f] };
         if (int rc = check_batch_planes(c, enc_planes[f], refs, 1)) return rc;
@@ -2232,8 +2237,10 @@ int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, 
         const int f0 = runs[k].f0, pm = part_mode ? part_mode[f0] : 0;
         int gw, gh;
         field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
-        const int parts = pm == 1 ? 2 : 1;
-        len[k] = (long)(parts * (gw + 2 * (gh / parts)) * (12.0 + 0.75 * sqrt((double)pu_w[f0] * pu_h[f0])));
+        const int parts = field_two_rows(pm) ? 2 : 1;
+        // (the two parts of an asymmetric CU together have the CU's area: half of it each on average)
+        const double area = (double)pu_w[f0] * pu_h[f0] * (pm >= 4 ? 0.5 : 1.0);
+        len[k] = (long)(parts * (gw + 2 * (gh / parts)) * (12.0 + 0.75 * sqrt(area)));
         by_len[k] = (int)k;
     }
     std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return len[a] > len[b]; });
@@ -2249,8 +2256,9 @@ int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, 
         int gw, gh;
         field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
         hipStream_t st = stream_of[k] == 0 ? c->stream : c->aux[stream_of[k] - 1];
-        const int cls = job_class(pu_w[f0], pu_h[f0]);
-        const int wg_rows = pm == 1 ? gh / 2 : gh;
+        // (the larger part of an asymmetric CU, three quarters of it, picks the kernel)
+        const int cls = pm >= 4 ? job_class(pu_w[f0], pu_h[f0] - (pu_h[f0] >> 2)) : job_class(pu_w[f0], pu_h[f0]);
+        const int wg_rows = field_two_rows(pm) ? gh / 2 : gh;
         x265amd_me_result *res = (x265amd_me_result*)c->field_results.p + first[f0];
         int *mvp = (int*)c->field_mvp.p + first[f0];
         const LookPair *pairs = (const LookPair*)c->look_pairs.p + f0;

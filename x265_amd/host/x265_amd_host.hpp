@@ -228,14 +228,45 @@ public:
         m_valid = true;
     }
     // One field per entry of `shapes` - a PU size and a partition mode each (x265amd_field_me_multi): the 2Nx2N fields of
-    // several quadtree depths and the 2NxN / Nx2N fields beside them, searched side by side in ONE device call and entered
-    // under the arguments predInterSearch would pass for each part (bounds from the CU's position).
+    // several quadtree depths and the 2NxN / Nx2N and asymmetric fields beside them, searched side by side in ONE device call
+    // and entered under the arguments predInterSearch would pass for each part (bounds from the CU's position).
+    // part_mode is a PartSize (Lib/TLibCommon/TypeDef.h:100-111): 0 2Nx2N, 1 2NxN (pu = the part), 2 Nx2N (pu = the part),
+    // 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N (pu = the CU, square, 16 / 32 / 64).
     struct Shape { int pu_w, pu_h, part_mode; };
+    static bool upperLower(int pm) { return pm == 1 || pm == 4 || pm == 5; }
     static void shapeGrid(const ReferencePlanes &enc, const Shape &s, int &gw, int &gh)
     {
         gw = enc.width / s.pu_w; gh = enc.height / s.pu_h;
         if (s.part_mode == 1) gh &= ~1;
         if (s.part_mode == 2) gw &= ~1;
+        if (s.part_mode == 4 || s.part_mode == 5) gh *= 2;
+        if (s.part_mode == 6 || s.part_mode == 7) gw *= 2;
+    }
+    // PU (gx, gy) of a shape's grid: its rectangle and the position of its CU
+    struct PuRect { int x, y, w, h, cuX, cuY; bool lower; };
+    static PuRect shapePu(const Shape &s, int gx, int gy)
+    {
+        PuRect r;
+        const int pm = s.part_mode;
+        r.lower = upperLower(pm) && (gy & 1);
+        r.x = gx * s.pu_w; r.y = gy * s.pu_h; r.w = s.pu_w; r.h = s.pu_h;
+        r.cuX = pm == 2 ? (gx & ~1) * s.pu_w : r.x;
+        r.cuY = pm == 1 && r.lower ? r.y - s.pu_h : r.y;
+        if (pm == 4 || pm == 5)
+        {
+            const int cut = pm == 4 ? s.pu_h >> 2 : s.pu_h - (s.pu_h >> 2);
+            r.cuY = (gy >> 1) * s.pu_h;
+            r.y = r.cuY + (r.lower ? cut : 0);
+            r.h = r.lower ? s.pu_h - cut : cut;
+        }
+        if (pm == 6 || pm == 7)
+        {
+            const int cut = pm == 6 ? s.pu_w >> 2 : s.pu_w - (s.pu_w >> 2);
+            r.cuX = (gx >> 1) * s.pu_w;
+            r.x = r.cuX + ((gx & 1) ? cut : 0);
+            r.w = (gx & 1) ? s.pu_w - cut : cut;
+        }
+        return r;
     }
     void runChained(const ReferencePlanes &enc, const ReferencePlanes &ref, const std::vector<Shape> &shapes, int merange, int method,
                     int subme, int qp)
@@ -267,10 +298,11 @@ public:
                 for (int gx = 0; gx < gw; gx++)
                 {
                     const int xy = gx + gy * gw;
-                    const bool lower = sh.part_mode == 1 && (gy & 1);
+                    const PuRect pu = shapePu(sh, gx, gy);
+                    const bool lower = pu.lower;
                     x265amd_me_job j = x265amd_me_job();
-                    j.pu_x = gx * sh.pu_w; j.pu_y = gy * sh.pu_h; j.w = (int16_t)sh.pu_w; j.h = (int16_t)sh.pu_h;
-                    const int cuX = sh.part_mode == 2 ? (gx & ~1) * sh.pu_w : j.pu_x, cuY = lower ? j.pu_y - sh.pu_h : j.pu_y;
+                    j.pu_x = pu.x; j.pu_y = pu.y; j.w = (int16_t)pu.w; j.h = (int16_t)pu.h;
+                    const int cuX = pu.cuX, cuY = pu.cuY;
                     MV p(mvp[2 * xy], mvp[2 * xy + 1]), lo, hi;
                     setSearchRange(p, merange, enc.width, enc.height, cuX, cuY, lo, hi);
                     j.mvmin_x = lo.x; j.mvmin_y = lo.y; j.mvmax_x = hi.x; j.mvmax_y = hi.y;
