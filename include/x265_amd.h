@@ -407,6 +407,19 @@ int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes
 int x265amd_field_me_multi(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w,
                            const int *pu_h, const int *part_mode, int merange, int method, int subme, int qp,
                            x265amd_me_result *out, int16_t *out_mvp);
+/* The same with the temporal AMVP candidate of TComDataCU::fillMvpCand (Lib/TLibCommon/TComDataCU.cpp:2635-2697).
+ *   col (NULL: none, x265amd_field_me_multi) = the co-located picture's motion for every field, one after the other: per field
+ *   ((width + 15) / 16) x ((height + 15) / 16) entries in raster order, one per 16x16 block (the granularity at which the encoder
+ *   keeps a coded picture's motion: xGetColMVP masks the partition address, :3010), already scaled to the field's picture /
+ *   reference distance (xGetDistScaleFactor :3079-3096 and scaleMv :45-51, as xGetColMVP applies them :3047-3075); cost < 0 marks a
+ *   block without motion (intra, or no MV in the list xGetColMVP would read).  Host memory, read before the call returns.
+ * Per PU the entry below-right of it is taken unless that position lies outside the picture or in the next CTU row (64), else -
+ * and when that block has no motion - the one at the PU's centre (xDeriveCenterIdx, :3104-3116).  The candidate follows the spatial
+ * ones unpruned and the list is cut to two (:2699-2702): it takes part where fewer than two spatial candidates exist (no left or no
+ * above neighbour, or both carrying the same MV - the common case in smooth motion). */
+int x265amd_field_me_multi_tmvp(x265amd_ctx *ctx, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w,
+                                const int *pu_h, const int *part_mode, const x265amd_me_result *col, int merange, int method,
+                                int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
 const x265amd_me_result *x265amd_field_results_device(const x265amd_ctx *ctx);
 
 /* number of block-cost evaluations executed by the search kernels since the counter was last

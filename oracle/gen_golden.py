@@ -36,8 +36,8 @@ class RefChain:
     def __init__(self, ref):
         self.ref = ref
 
-    def field_run(self, enc, refp, pw, ph, mr, method, subme, qp, part_mode=0):
-        return self.ref.field_me(enc, refp, pw, ph, mr, method, subme, qp, part_mode=part_mode)
+    def field_run(self, enc, refp, pw, ph, mr, method, subme, qp, part_mode=0, col=None):
+        return self.ref.field_me(enc, refp, pw, ph, mr, method, subme, qp, part_mode=part_mode, col=col)
 
 
 def gen_chain():
@@ -48,6 +48,7 @@ def gen_chain():
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_u%d.npz" % bits), **G.run_chain_suite(RefChain(ref), bits))
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_parts_u%d.npz" % bits), **G.run_chain_parts_suite(RefChain(ref), bits))
         np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_amp_u%d.npz" % bits), **G.run_chain_amp_suite(RefChain(ref), bits))
+        np.savez_compressed(os.path.join(G.GOLDEN_DIR, "chain_tmvp_u%d.npz" % bits), **G.run_chain_tmvp_suite(RefChain(ref), bits))
         print("chain fields, bits", bits)
 
 

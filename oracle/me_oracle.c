@@ -154,12 +154,33 @@ int64_t meo_lookahead_me(const meo_plane *enc, const meo_plane *ref, int cuw, in
                                   : lookahead_me_u16(enc, ref, cuw, cuh, merange, method, subme, qp, out);
 }
 
+int64_t meo_field_me_tmvp(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
+                          const meo_result *col, int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
+{
+    cost_table_for_qp(qp);
+    return enc->bytes_per_px == 1 ? field_me_u8(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, col, merange, method, subme, qp, out, out_mvp)
+                                  : field_me_u16(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, col, merange, method, subme, qp, out, out_mvp);
+}
+
 int64_t meo_field_me_parts(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
                            int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
 {
-    cost_table_for_qp(qp);
-    return enc->bytes_per_px == 1 ? field_me_u8(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, merange, method, subme, qp, out, out_mvp)
-                                  : field_me_u16(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, merange, method, subme, qp, out, out_mvp);
+    return meo_field_me_tmvp(enc, ref, pic_w, pic_h, pu_w, pu_h, part_mode, NULL, merange, method, subme, qp, out, out_mvp);
+}
+
+/* TComDataCU::xGetDistScaleFactor (TComDataCU.cpp:3079-3096) and scaleMv (:45-51) as xGetColMVP applies them (:3066-3074) */
+void meo_scale_col_mv(int cur_poc, int cur_ref_poc, int col_poc, int col_ref_poc, int16_t *mvx, int16_t *mvy)
+{
+    const int d = col_poc - col_ref_poc, b = cur_poc - cur_ref_poc;
+    if (d == b)
+        return;
+    const int tdb = b < -128 ? -128 : b > 127 ? 127 : b, tdd = d < -128 ? -128 : d > 127 ? 127 : d;
+    const int x = (0x4000 + abs(tdd / 2)) / tdd;
+    int scale = (tdb * x + 32) >> 6;
+    scale = scale < -4096 ? -4096 : scale > 4095 ? 4095 : scale;
+    int vx = (scale * *mvx + 127 + (scale * *mvx < 0)) >> 8, vy = (scale * *mvy + 127 + (scale * *mvy < 0)) >> 8;
+    *mvx = (int16_t)(vx < -32768 ? -32768 : vx > 32767 ? 32767 : vx);
+    *mvy = (int16_t)(vy < -32768 ? -32768 : vy > 32767 ? 32767 : vy);
 }
 
 int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int merange,

@@ -122,6 +122,14 @@ int64_t meo_field_me(const meo_plane *enc, const meo_plane *ref, int pic_w, int 
  * 2c / 2c + 1 the left / right parts (6, 7: 2 (pic_w / pu_w) PUs per row) */
 int64_t meo_field_me_parts(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
                            int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
+/* the same with the temporal AMVP candidate (TComDataCU::fillMvpCand, Lib/TLibCommon/TComDataCU.cpp:2635-2697): col = the co-located
+ * picture's motion per 16x16 block, ((pic_w + 15) / 16) x ((pic_h + 15) / 16) entries in raster order, scaled already to this
+ * picture's reference distance (meo_scale_col_mv), cost < 0 where the block has none; it is taken below-right of the PU, else at
+ * the PU's centre, and joins the list while that holds fewer than two spatial candidates.  col == NULL: as above. */
+int64_t meo_field_me_tmvp(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
+                          const meo_result *col, int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp);
+/* the scaling of a co-located MV by the POC distances (xGetDistScaleFactor :3079-3096, scaleMv :45-51), in place */
+void meo_scale_col_mv(int cur_poc, int cur_ref_poc, int col_poc, int col_ref_poc, int16_t *mvx, int16_t *mvy);
 
 /* run n jobs (one enc plane, jobs[i].ref_idx selects refs[]) with `threads` OpenMP threads
  * (one search state per thread); returns total number of block-cost evaluations. */

@@ -1119,6 +1119,8 @@ static inline int SUF(clipi)(int v, int lo, int hi)
  * candidate (xEstimateMvPredAMVP :2767-2819, xGetTemplateCost :2944-2958, TComDataCU::clipMv
  * TComDataCU.cpp:2724-2736; equal index bits, ties keep the first); range = xSetSearchRange (:3007-3024);
  * motionEstimate with the three neighbour MVs m_mvPredictors (:2366-2368) as candidates.
+ * col (optional): the co-located picture's motion, one entry per 16x16 block in raster order ((pic_w + 15) / 16 per row), already
+ * scaled to this picture / reference distance (xGetColMVP, :3008-3077); cost < 0 = the block has none (intra, other list empty).
  * part_mode 0: every PU is the 2Nx2N PU of its own CU.  1 (2NxN): CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 their upper /
  * lower parts; 2 (Nx2N): CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts; the parts of a CU are
  * searched one after the other (the partIdx loop, :2341).  clipMv / xSetSearchRange take the CU's position.  Where the
@@ -1131,7 +1133,7 @@ static inline int SUF(clipi)(int v, int lo, int hi)
  * deriveLeftBottomIdxGeneral (TComDataCU.cpp:1837-1944), and the neighbours are those of mode 1 / mode 2 (the cut moves, the
  * CUs the corner positions fall into do not).  PU rows 2r / 2r + 1 (columns 2c / 2c + 1) are the two parts, as there. */
 static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic_w, int pic_h, int pu_w, int pu_h, int part_mode,
-                             int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
+                             const meo_result *col, int merange, int method, int subme, int qp, meo_result *out, int16_t *out_mvp)
 {
     SUF(state) *st = (SUF(state)*)malloc(sizeof(SUF(state)));
     int64_t evals = 0;
@@ -1176,17 +1178,44 @@ static int64_t SUF(field_me)(const meo_plane *enc, const meo_plane *ref, int pic
             if (have_ar)      { bx = out[xy - gw + 1].mvx; by = out[xy - gw + 1].mvy; have_b = 1; }
             else if (have_a)  { bx = out[xy - gw].mvx;     by = out[xy - gw].mvy;     have_b = 1; }
             else if (have_al) { bx = out[xy - gw - 1].mvx; by = out[xy - gw - 1].mvy; have_b = 1; }
+            int n_cand = 0;
             if (have_l)
             {
                 c[0][0] = out[xa].mvx; c[0][1] = out[xa].mvy;
+                n_cand = 1;
                 if (have_b && !(bx == c[0][0] && by == c[0][1]))
                 {
                     c[1][0] = bx; c[1][1] = by;
+                    n_cand = 2;
                 }
             }
             else if (have_b)
             {
                 c[0][0] = bx; c[0][1] = by;
+                n_cand = 1;
+            }
+            if (col && n_cand < 2)
+            {
+                /* the temporal candidate (fillMvpCand, TComDataCU.cpp:2635-2697): the co-located motion below-right of the PU
+                 * unless that lies outside the picture or in the next CTU row, else (also when that block has none) at the
+                 * PU's centre; motion is kept per 16x16 block (xGetColMVP masks the address, :3010).  It goes in unpruned;
+                 * the list is then cut to two (:2699-2702), so it counts only while there is room. */
+                const int cw = (pic_w + 15) >> 4;
+                const int rbx = px + bw, rby = py + bh;
+                const meo_result *t = NULL;
+                if (rbx < pic_w && rby < pic_h && (rby & (max_cu - 1)) != 0 && col[(rby >> 4) * cw + (rbx >> 4)].cost >= 0)
+                    t = &col[(rby >> 4) * cw + (rbx >> 4)];
+                else
+                {
+                    const int ctx = px + ((bw >> 3) << 2), cty = py + ((bh >> 3) << 2);       /* xDeriveCenterIdx, :3104-3116 */
+                    if (col[(cty >> 4) * cw + (ctx >> 4)].cost >= 0)
+                        t = &col[(cty >> 4) * cw + (ctx >> 4)];
+                }
+                if (t)
+                {
+                    c[n_cand][0] = t->mvx; c[n_cand][1] = t->mvy;
+                    n_cand++;
+                }
             }
             const int xmax = (pic_w + 8 - cux - 1) << 2, xmin = (-max_cu - 8 - cux + 1) << 2;
             const int ymax = (pic_h + 8 - cuy - 1) << 2, ymin = (-max_cu - 8 - cuy + 1) << 2;

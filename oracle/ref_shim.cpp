@@ -395,8 +395,15 @@ static inline void shim_clip(MV &mv, int picw, int pich, int px, int py)
  * has the upper part above it and nothing coded above-right.  4 / 5 / 6 / 7: the parts of 2NxnU / 2NxnD / nLx2N / nRx2N CUs of
  * puw x puh (sizes and corner positions: deriveLeftRightTopIdxGeneral / deriveLeftBottomIdxGeneral, TComDataCU.cpp:1837-1944);
  * their neighbours are those of partMode 1 / 2. */
-void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh, int partMode,
-                        int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
+struct ShimColMv { int16_t x, y; int32_t cost; };      /* one 16x16 block of the co-located picture; cost < 0: no motion */
+
+/* colMvs (optional): the temporal candidate of fillMvpCand (TComDataCU.cpp:2635-2697) from the co-located picture's motion per
+ * 16x16 block (xGetColMVP masks the partition address to that granularity, :3010), (picw + 15) / 16 entries per row, scaled
+ * already: taken below-right of the PU unless that is outside the picture or in the next CTU row, else - and when that block
+ * has no motion - at the PU's centre (xDeriveCenterIdx, :3104-3116); appended unpruned, the list is cut to two (:2699-2702). */
+void ref_field_me_tmvp(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh, int partMode,
+                       const ShimColMv *colMvs, int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost,
+                       int16_t *out_mvp)
 {
     RefME *r = (RefME*)h;
     r->me.setQP(qp);
@@ -452,13 +459,30 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
             MV cand[2], b;
             bool haveB = haveAR || haveA || haveAL;
             if (haveAR) b = mvs[xy - gw + 1]; else if (haveA) b = mvs[xy - gw]; else if (haveAL) b = mvs[xy - gw - 1];
+            int numCand = 0;
             if (haveL)
             {
-                cand[0] = (horiz && !lower) ? mvs[xy + gw - 1] : mvs[xy - 1];
-                if (haveB && b != cand[0]) cand[1] = b;
+                cand[numCand++] = (horiz && !lower) ? mvs[xy + gw - 1] : mvs[xy - 1];
+                if (haveB && b != cand[0]) cand[numCand++] = b;
             }
             else if (haveB)
-                cand[0] = b;
+                cand[numCand++] = b;
+            if (colMvs && numCand < 2)
+            {
+                const int cw = (picw + 15) >> 4;
+                const int rbx = px + bw, rby = py + bh;
+                const ShimColMv *t = NULL;
+                if (rbx < picw && rby < pich && (rby & 63) && colMvs[(rby >> 4) * cw + (rbx >> 4)].cost >= 0)
+                    t = &colMvs[(rby >> 4) * cw + (rbx >> 4)];
+                else
+                {
+                    const int ctrx = px + (bw / 4 / 2) * 4, ctry = py + (bh / 4 / 2) * 4;
+                    if (colMvs[(ctry >> 4) * cw + (ctrx >> 4)].cost >= 0)
+                        t = &colMvs[(ctry >> 4) * cw + (ctrx >> 4)];
+                }
+                if (t)
+                    cand[numCand++] = MV(t->x, t->y);
+            }
             MV mvp = cand[0];
             if (cand[1] != cand[0])
             {
@@ -512,6 +536,12 @@ void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int pi
     }
     delete[] tmp;
     delete[] mvs;
+}
+
+void ref_field_me_parts(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh, int partMode,
+                        int merange, int method, int subme, int qp, int16_t *out_mv, int *out_cost, int16_t *out_mvp)
+{
+    ref_field_me_tmvp(h, enc, ref, stride, picw, pich, puw, puh, partMode, NULL, merange, method, subme, qp, out_mv, out_cost, out_mvp);
 }
 
 void ref_field_me(void *h, pixel *enc, pixel *ref, intptr_t stride, int picw, int pich, int puw, int puh,

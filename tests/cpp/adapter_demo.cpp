@@ -192,7 +192,8 @@ int main(int argc, char **argv)
         // (8) fields of several PU sizes and partition modes from ONE device call: the 2Nx2N fields of the 16x16 and 32x32 CUs, the
         //     2NxN / Nx2N fields of the 16x16 CUs, the 2NxnU field of the 32x32 and the nRx2N field of the 16x16 CUs.  For each an "encoder" that codes every CU in that mode walks the CUs in
         //     raster order, part by part, derives the predictors from its own decisions by the rules of the partition mode and
-        //     calls motionEstimate at the unchanged call site.  One part per field is "coded intra".
+        //     calls motionEstimate at the unchanged call site.  One part per field is "coded intra".  The AMVP lists take the
+        //     temporal candidate from a co-located motion field, on the device and in the walk alike.
         {
             typedef x265amd::MotionField::Shape Shape;
             const std::vector<Shape> shapes = { Shape{ 16, 16, 0 }, Shape{ 32, 32, 0 }, Shape{ 16, 8, 1 }, Shape{ 8, 16, 2 },
@@ -202,7 +203,21 @@ int main(int argc, char **argv)
             me.setSearchMethod(1);
             me.setSubpelRefine(3);
             me.setQP(28);
-            field.runChained(pe, pr, shapes, merange, 1, 3, 28);
+            // The co-located motion (the temporal AMVP candidate's source): one MV per 16x16 block of a "previous picture" twice as
+            // far from its reference as this one is, so every MV is scaled to half; every ninth block was "coded intra".
+            const int colW = (W + 15) / 16, colH = (H + 15) / 16;
+            std::vector<x265amd_me_result> colOne(colW * colH);
+            unsigned lcg = 12345;
+            for (size_t i = 0; i < colOne.size(); i++)
+            {
+                lcg = lcg * 1664525u + 1013904223u;
+                const x265amd::MV m = x265amd::scaleColMv(x265amd::MV((int16_t)((lcg >> 8) % 41) - 20, (int16_t)((lcg >> 16) % 25) - 12), 2, 1, 1, -1);
+                colOne[i].mvx = m.x; colOne[i].mvy = m.y; colOne[i].cost = i % 9 == 4 ? -1 : 0;
+            }
+            std::vector<x265amd_me_result> col;
+            for (size_t f = 0; f < shapes.size(); f++)
+                col.insert(col.end(), colOne.begin(), colOne.end());
+            field.runChained(pe, pr, shapes, merange, 1, 3, 28, &col);
             me.attachField(&field);
             int total = 0;
             for (size_t f = 0; f < shapes.size(); f++)
@@ -210,6 +225,8 @@ int main(int argc, char **argv)
                 const Shape &sh = shapes[f];
                 int gw, gh;
                 x265amd::MotionField::shapeGrid(pe, sh, gw, gh);
+                const unsigned hits0 = field.hits();
+                const int total0 = total;
                 const bool twoRows = x265amd::MotionField::upperLower(sh.part_mode);
                 const int parts = twoRows ? 2 : 1;
                 std::vector<x265amd::MV> dec(gw * gh);
@@ -231,8 +248,25 @@ int main(int argc, char **argv)
                             if (haveAR) b = dec[xy - gw + 1]; else if (haveA) b = dec[xy - gw]; else if (haveAL) b = dec[xy - gw - 1];
                             // (upper part of a 2NxN / 2NxnU / 2NxnD CU: the left scan finds the below-left neighbour first)
                             const x265amd::MV a = haveL ? ((twoRows && !lower) ? dec[xy + gw - 1] : dec[xy - 1]) : x265amd::MV();
-                            if (haveL) { cand[0] = a; if (haveB && b != cand[0]) cand[1] = b; }
-                            else if (haveB) cand[0] = b;
+                            int numCand = 0;
+                            if (haveL) { cand[numCand++] = a; if (haveB && b != cand[0]) cand[numCand++] = b; }
+                            else if (haveB) cand[numCand++] = b;
+                            if (numCand < 2)
+                            {
+                                // the temporal candidate: below-right of the PU (inside the picture and the CTU row), else its centre
+                                const int rbx = px + pu.w, rby = py + pu.h;
+                                const x265amd_me_result *t = NULL;
+                                if (rbx < W && rby < H && (rby & 63) && colOne[(rby >> 4) * colW + (rbx >> 4)].cost >= 0)
+                                    t = &colOne[(rby >> 4) * colW + (rbx >> 4)];
+                                else
+                                {
+                                    const int ctrx = px + pu.w / 8 * 4, ctry = py + pu.h / 8 * 4;
+                                    if (colOne[(ctry >> 4) * colW + (ctrx >> 4)].cost >= 0)
+                                        t = &colOne[(ctry >> 4) * colW + (ctrx >> 4)];
+                                }
+                                if (t)
+                                    cand[numCand++] = x265amd::MV(t->mvx, t->mvy);
+                            }
                             x265amd::MV mvp = cand[0];
                             if (cand[1] != cand[0])
                             {
@@ -243,14 +277,16 @@ int main(int argc, char **argv)
                             }
                             x265amd::MV lo, hi, out;
                             x265amd::setSearchRange(mvp, merange, W, H, cuX, cuY, lo, hi);
+                            const unsigned hitsBefore = field.hits();
                             int cost = me.motionEstimate(&pr, lo, hi, mvp, 3, pred, merange, out);
                             const bool intra = xy == 21;
                             dec[xy] = intra ? x265amd::MV(0, 0) : out;
                             total++;
-                            printf("mchain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", pu.w, pu.h, sh.part_mode, px, py,
+                            printf("mchain %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %u\n", pu.w, pu.h, sh.part_mode, px, py,
                                    mvp.x, mvp.y, lo.x, lo.y, hi.x, hi.y, pred[0].x, pred[0].y, pred[1].x, pred[1].y, pred[2].x, pred[2].y,
-                                   out.x, out.y, cost, intra ? 1 : 0);
+                                   out.x, out.y, cost, intra ? 1 : 0, field.hits() - hitsBefore);
                         }
+                printf("mchainshape %d %d %d %u %d\n", sh.pu_w, sh.pu_h, sh.part_mode, field.hits() - hits0, total - total0);
             }
             printf("mchainstats %u %u %d\n", field.hits(), field.misses(), total);
             me.attachField(NULL);

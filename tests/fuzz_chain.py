@@ -93,17 +93,26 @@ def main():
             ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
             if method == 2 and pw * ph == 16:       # (UMH has no 4x4)
                 method = 1
-            got, got_mvp = eng.field_me_multi([ids[1]], [ids[0]], [pw], [ph], [pm], merange, method, subme, qp)[0]
-            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth, part_mode=pm)
+            col = None
+            if rng.random() < 0.5:                  # a co-located motion field for the temporal candidate
+                from x265_amd.jobs import RESULT_DTYPE
+                nb = ((w + 15) // 16) * ((h + 15) // 16)
+                col = np.zeros(nb, dtype=RESULT_DTYPE)
+                spread = int(rng.choice([3, 12, 60]))
+                col["mvx"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
+                col["mvy"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
+                col["cost"] = np.where(rng.random(nb) < rng.choice([0.0, 0.2, 0.7]), -1, 0)
+            got, got_mvp = eng.field_me_multi([ids[1]], [ids[0]], [pw], [ph], [pm], merange, method, subme, qp, col=col)[0]
+            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth, part_mode=pm, col=col)
             if not (np.array_equal(got, exp) and np.array_equal(got_mvp, exp_mvp)):
-                print("MISMATCH field %dx%d PU %dx%d mode %d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
-                      % (w, h, pw, ph, pm, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
+                print("MISMATCH field (col %s) %dx%d PU %dx%d mode %d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
+                      % (col is not None, w, h, pw, ph, pm, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
                 sys.exit(1)
             for p in ids:
                 eng.release_plane(p)
             n_field += 1
             pus += got.size
-            what = "field %4dx%-4d PU %2dx%-2d mode %d" % (w, h, pw, ph, pm)
+            what = "field %4dx%-4d PU %2dx%-2d mode %d%s" % (w, h, pw, ph, pm, " +col" if col is not None else "")
         if (n_look + n_field) % 20 == 0:
             print("case %d ok: %s %2d-bit depth %2d %-6s (%d s)" % (n_look + n_field, what, bits, depth, kind, time.time() - t0), flush=True)
     print("chained-path campaign: %d lookahead cases (%d CU searches) and %d chained fields (%d PU searches), all bit-exact against "

@@ -300,3 +300,34 @@ def run_chain_amp_suite(impl, bits: int) -> dict:
         out["res%d" % k] = np.ascontiguousarray(res)
         out["mvp%d" % k] = np.ascontiguousarray(mvp)
     return out
+
+
+# the same with the temporal AMVP candidate (TComDataCU::fillMvpCand, Lib/TLibCommon/TComDataCU.cpp:2635-2697): a co-located
+# motion field per 16x16 block (a common drift plus noise, a fifth of the blocks without motion) joins the candidate list where
+# fewer than two spatial candidates exist: (pu_w, pu_h, part_mode, merange, method, subme, qp, content)
+CHAIN_TMVP_CASES = ((16, 16, 0, 32, J.HEX, 5, 30, "motion"), (8, 8, 0, 16, J.DIA, 2, 24, "motion"), (32, 32, 0, 24, J.STAR, 3, 35, "noise"),
+                    (64, 64, 0, 16, J.UMH, 1, 28, "motion"), (16, 8, 1, 20, J.HEX, 7, 32, "motion"), (8, 16, 2, 12, J.UMH, 4, 27, "motion"),
+                    (32, 32, 4, 24, J.HEX, 3, 31, "motion"), (16, 16, 7, 16, J.STAR, 2, 29, "noise"), (64, 64, 5, 8, J.FULL, 0, 30, "motion"),
+                    (32, 32, 6, 16, J.DIA, 6, 33, "motion"), (8, 4, 1, 8, J.HEX, 1, 26, "motion"))
+
+
+def chain_col_field(bits: int, k: int):
+    rng = np.random.default_rng(9000 + bits + 17 * k)
+    n = ((CHAIN_W + 15) // 16) * ((CHAIN_H + 15) // 16)
+    col = np.zeros(n, dtype=J.RESULT_DTYPE)
+    drift = rng.integers(-14, 15, 2)
+    col["mvx"] = drift[0] + rng.integers(-5, 6, n)
+    col["mvy"] = drift[1] + rng.integers(-5, 6, n)
+    col["cost"] = np.where(rng.random(n) < 0.2, -1, 0)
+    return col
+
+
+def run_chain_tmvp_suite(impl, bits: int) -> dict:
+    """impl.field_run(enc, ref, pu_w, pu_h, merange, method, subme, qp, part_mode=m, col=c) -> (results[gh, gw], mvp[gh, gw, 2])"""
+    out = {}
+    for k, (pw, ph, pm, mr, method, subme, qp, kind) in enumerate(CHAIN_TMVP_CASES):
+        fr = chain_frames(bits, kind)
+        res, mvp = impl.field_run(fr[1], fr[0], pw, ph, mr, method, subme, qp, part_mode=pm, col=chain_col_field(bits, k))
+        out["res%d" % k] = np.ascontiguousarray(res)
+        out["mvp%d" % k] = np.ascontiguousarray(mvp)
+    return out

@@ -144,8 +144,15 @@ class Oracle:
         ref = self.make_plane(ref_padded, bit_depth, margin)
         return self.lib.meo_mc_cost(C.byref(enc), C.byref(ref), pu_x, pu_y, w, h, qx, qy, kind)
 
+    def scale_col_mv(self, cur_poc, cur_ref_poc, col_poc, col_ref_poc, mvx, mvy):
+        """xGetColMVP's scaling of a co-located MV by the POC distances"""
+        x, y = C.c_int16(mvx), C.c_int16(mvy)
+        self.lib.meo_scale_col_mv.restype = None
+        self.lib.meo_scale_col_mv(cur_poc, cur_ref_poc, col_poc, col_ref_poc, C.byref(x), C.byref(y))
+        return x.value, y.value
+
     def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, bit_depth=None, margin: int = MARGIN,
-                 part_mode: int = 0):
+                 part_mode: int = 0, col=None):
         """(results[gh, gw], mvp[gh, gw, 2], evals) of the whole-frame field with predInterSearch's predictor chain
         (part_mode 1 / 2: the parts of 2NxN / Nx2N CUs, 4..7: of 2NxnU / 2NxnD / nLx2N / nRx2N CUs of pu_w x pu_h)"""
         enc = self.make_plane(enc_padded, bit_depth, margin)
@@ -154,9 +161,13 @@ class Oracle:
         gw, gh = field_grid(pw, ph, pu_w, pu_h, part_mode)
         out = np.zeros((gh, gw), dtype=RESULT_DTYPE)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)
-        self.lib.meo_field_me_parts.restype = C.c_int64
-        ev = self.lib.meo_field_me_parts(C.byref(enc), C.byref(ref), pw, ph, pu_w, pu_h, part_mode, merange, method, subme, qp,
-                                         out.ctypes.data_as(C.c_void_p), mvp.ctypes.data_as(C.c_void_p))
+        if col is not None:                 # (the co-located picture's motion per 16x16 block, RESULT_DTYPE, cost < 0 = none)
+            col = np.ascontiguousarray(col, dtype=RESULT_DTYPE)
+            assert col.size == ((pw + 15) // 16) * ((ph + 15) // 16)
+        self.lib.meo_field_me_tmvp.restype = C.c_int64
+        ev = self.lib.meo_field_me_tmvp(C.byref(enc), C.byref(ref), pw, ph, pu_w, pu_h, part_mode,
+                                        col.ctypes.data_as(C.c_void_p) if col is not None else None, merange, method, subme, qp,
+                                        out.ctypes.data_as(C.c_void_p), mvp.ctypes.data_as(C.c_void_p))
         return out, mvp, ev
 
     def search(self, enc_padded, ref_padded_list, jobs, threads=1, bit_depth=None, margin: int = MARGIN, lowres=False):
@@ -276,7 +287,8 @@ class Reference:
         out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
         return out
 
-    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, margin: int = MARGIN, part_mode: int = 0):
+    def field_me(self, enc_padded, ref_padded, pu_w, pu_h, merange, method, subme, qp, margin: int = MARGIN, part_mode: int = 0,
+                 col=None):
         """(results[gh, gw], mvp[gh, gw, 2]): the reference's MotionEstimate driven over a PU grid with
         predInterSearch's predictor chain (oracle/ref_shim.cpp: ref_field_me_parts)"""
         pw, ph = enc_padded.shape[1] - 2 * margin, enc_padded.shape[0] - 2 * margin
@@ -285,11 +297,15 @@ class Reference:
         cost = np.zeros(gh * gw, dtype=np.int32)
         mvp = np.zeros((gh, gw, 2), dtype=np.int16)
         assert enc_padded.shape == ref_padded.shape
-        self.lib.ref_field_me_parts.restype = None
-        self.lib.ref_field_me_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t] + [C.c_int] * 9 + [C.c_void_p] * 3
-        self.lib.ref_field_me_parts(self.me, plane_origin(enc_padded, margin), plane_origin(ref_padded, margin), enc_padded.shape[1],
-                                    pw, ph, pu_w, pu_h, part_mode, merange, method, subme, qp, mv.ctypes.data, cost.ctypes.data,
-                                    mvp.ctypes.data)
+        if col is not None:
+            col = np.ascontiguousarray(col, dtype=RESULT_DTYPE)
+            assert col.size == ((pw + 15) // 16) * ((ph + 15) // 16)
+        self.lib.ref_field_me_tmvp.restype = None
+        self.lib.ref_field_me_tmvp.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t] + [C.c_int] * 5 + [C.c_void_p] +
+                                               [C.c_int] * 4 + [C.c_void_p] * 3)
+        self.lib.ref_field_me_tmvp(self.me, plane_origin(enc_padded, margin), plane_origin(ref_padded, margin), enc_padded.shape[1],
+                                   pw, ph, pu_w, pu_h, part_mode, col.ctypes.data if col is not None else None,
+                                   merange, method, subme, qp, mv.ctypes.data, cost.ctypes.data, mvp.ctypes.data)
         out = np.zeros(gh * gw, dtype=RESULT_DTYPE)
         out["mvx"], out["mvy"], out["cost"] = mv[:, 0], mv[:, 1], cost
         return out.reshape(gh, gw), mvp

@@ -24,10 +24,10 @@ class GpuChain:
     def __init__(self, eng, bits):
         self.eng, self.depth = eng, 8 if bits == 8 else 10
 
-    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0):
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0, col=None):
         ids = [self.eng.upload_plane(enc, bit_depth=self.depth), self.eng.upload_plane(ref, bit_depth=self.depth)]
-        if part_mode:
-            out = self.eng.field_me_multi([ids[0]], [ids[1]], [pw], [ph], [part_mode], mr, method, subme, qp)[0]
+        if part_mode or col is not None:
+            out = self.eng.field_me_multi([ids[0]], [ids[1]], [pw], [ph], [part_mode], mr, method, subme, qp, col=col)[0]
         else:
             out = self.eng.field_me(ids[0], ids[1], pw, ph, mr, method, subme, qp)
         for i in ids:
@@ -66,6 +66,61 @@ def test_predictor_chain_fields_of_asymmetric_parts_match_reference_vectors(eng,
     assert set(gold.files) == set(got.keys())
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_with_temporal_candidate_match_reference_vectors(eng, bits):
+    """x265amd_field_me_multi_tmvp: a co-located motion field per 16x16 block supplies the temporal AMVP candidate (below-right of
+    the PU, else its centre) where fewer than two spatial candidates exist; against the fixtures made by the compiled reference
+    under the same driver: 2Nx2N, 2NxN, Nx2N and asymmetric parts"""
+    gold = np.load(os.path.join(G.GOLDEN_DIR, "chain_tmvp_u%d.npz" % bits), allow_pickle=False)
+    got = G.run_chain_tmvp_suite(GpuChain(eng, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+def test_1080p_fields_with_a_co_located_field_each_in_one_call(eng, oracle):
+    """one call, one 1080p frame, four fields (16x16 2Nx2N, 32x32 2NxnD, 8x8, 16x8 2NxN), each with a co-located motion field of
+    its own - here the 16x16 field of the previous frame pair scaled to twice / half / the opposite distance - and one without
+    motion anywhere (equal to no temporal candidate); every field and the evaluation total equal the oracle's"""
+    W, H = 1920, 1080
+    fr = synth.make_sequence(W, H, 3, seed=94)
+    ids = [eng.upload_plane(f) for f in fr]
+    prev, _ = eng.field_me(ids[1], ids[0], 16, 16, 32, J.HEX, 3, 30)         # the "coded" motion of the previous picture
+    cw, ch = (W + 15) // 16, (H + 15) // 16
+    base = np.zeros((ch, cw), dtype=J.RESULT_DTYPE)
+    base["cost"] = -1
+    base[:prev.shape[0], :prev.shape[1]] = prev
+    base["cost"][::7, ::5] = -1                                               # some "intra" blocks
+
+    def scaled(cur, cur_ref, col, col_ref):
+        c = base.copy()
+        for e in c.reshape(-1):
+            if e["cost"] >= 0:
+                e["mvx"], e["mvy"] = oracle.scale_col_mv(cur, cur_ref, col, col_ref, int(e["mvx"]), int(e["mvy"]))
+        return c.reshape(-1)
+
+    none = base.copy().reshape(-1)
+    none["cost"] = -1
+    shapes = [(16, 16, 0), (32, 32, 5), (8, 8, 0), (16, 8, 1), (16, 16, 0)]
+    cols = [scaled(2, 1, 1, 0), scaled(3, 1, 1, 0), scaled(2, 1, 1, -1), scaled(2, 3, 1, 0), none]
+    n = len(shapes)
+    eng.eval_count(reset=True)
+    got = eng.field_me_multi([ids[2]] * n, [ids[1]] * n, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes],
+                             32, J.HEX, 3, 30, col=np.stack(cols))
+    total = 0
+    for (pw, ph, pm), col, (res, mvp) in zip(shapes, cols, got):
+        exp, exp_mvp, evals = oracle.field_me(fr[2], fr[1], pw, ph, 32, J.HEX, 3, 30, part_mode=pm, col=col)
+        assert np.array_equal(res, exp), ((pw, ph, pm), np.argwhere(res != exp)[:5])
+        assert np.array_equal(mvp, exp_mvp), (pw, ph, pm)
+        total += evals
+    assert eng.eval_count() == total
+    plain, plain_mvp, _ = oracle.field_me(fr[2], fr[1], 16, 16, 32, J.HEX, 3, 30)
+    assert np.array_equal(got[4][1], plain_mvp) and np.array_equal(got[4][0], plain)
+    assert not np.array_equal(got[0][1], plain_mvp)                           # the candidate decides some predictors
+    for i in ids:
+        eng.release_plane(i)
 
 
 def test_1080p_asymmetric_fields_beside_the_square_ones_in_one_call(eng, oracle):

@@ -102,8 +102,8 @@ class OracleChain:
     def __init__(self, oracle, bits):
         self.o, self.depth = oracle, 8 if bits == 8 else 10
 
-    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0):
-        return self.o.field_me(enc, ref, pw, ph, mr, method, subme, qp, bit_depth=self.depth, part_mode=part_mode)[:2]
+    def field_run(self, enc, ref, pw, ph, mr, method, subme, qp, part_mode=0, col=None):
+        return self.o.field_me(enc, ref, pw, ph, mr, method, subme, qp, bit_depth=self.depth, part_mode=part_mode, col=col)[:2]
 
 
 @pytest.mark.parametrize("bits", [8, 16])
@@ -138,4 +138,30 @@ def test_predictor_chain_fields_of_asymmetric_parts_match_reference_vectors(orac
     assert set(gold.files) == set(got.keys())
     for k in gold.files:
         assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_predictor_chain_fields_with_temporal_candidate_match_reference_vectors(oracle, bits):
+    """the temporal AMVP candidate: a co-located motion field per 16x16 block, looked up below-right of the PU (not across
+    the picture edge or into the next CTU row) or else at its centre, joins the list while fewer than two spatial candidates
+    exist; 2Nx2N, 2NxN, Nx2N and asymmetric parts"""
+    gold = _load("chain_tmvp_u%d.npz" % bits)
+    got = G.run_chain_tmvp_suite(OracleChain(oracle, bits), bits)
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], got[k]), (k, np.argwhere(gold[k] != got[k])[:3])
+    # the candidate matters: the fields differ from those searched without it
+    plain = G.run_chain_tmvp_suite(type("NoCol", (), {"field_run": lambda self, *a, col=None, **kw: OracleChain(oracle, bits).field_run(*a, **kw)})(), bits)
+    assert sum(not np.array_equal(plain[k], got[k]) for k in got if k.startswith("mvp")) >= 8
+
+
+def test_col_mv_scaling_follows_the_poc_distances(oracle):
+    """xGetDistScaleFactor / scaleMv: equal distances leave the MV alone; twice the distance doubles it; half the distance halves
+    it, a half rounding towards zero ((scale * mv + 127 + (scale * mv < 0)) >> 8); the opposite direction mirrors it; the factor saturates at +-16 (4095 / 256) and the result at
+    the int16 range"""
+    assert oracle.scale_col_mv(8, 4, 6, 2, 13, -7) == (13, -7)
+    assert oracle.scale_col_mv(8, 4, 6, 4, 13, -7) == (26, -14)
+    assert oracle.scale_col_mv(8, 6, 6, 2, 13, -7) == (6, -3)
+    assert oracle.scale_col_mv(8, 10, 6, 4, 13, -7) == (-13, 7)
+    assert oracle.scale_col_mv(100, 0, 6, 5, 100, -3000) == (1600, -32768)
 

@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
     L.x265amd_field_me.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_me_batch.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_me_multi.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
+    L.x265amd_field_me_multi_tmvp.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     L.x265amd_field_results_device.argtypes = [vp]
     L.x265amd_field_results_device.restype = vp
     L.x265amd_plane_device_ptr.argtypes = [vp, ci]
@@ -327,9 +328,11 @@ class Engine:
         return (gw & ~1 if part_mode == 2 else gw), (gh & ~1 if part_mode == 1 else gh)
 
     def field_me_multi(self, enc_planes, ref_planes, pu_w, pu_h, part_mode, merange: int, method: int, subme: int, qp: int,
-                       fetch: bool = True):
+                       fetch: bool = True, col=None):
         """fields of DIFFERENT PU sizes / partition modes in one call (one per quadtree depth, say), run side by side;
-        returns a list of (results[gh, gw], mvp[gh, gw, 2]) per field, or None with fetch=False"""
+        returns a list of (results[gh, gw], mvp[gh, gw, 2]) per field, or None with fetch=False.
+        col: the co-located motion for the temporal AMVP candidate, RESULT_DTYPE[n_fields, 16x16 blocks of the picture in raster
+        order], scaled already, cost < 0 = none (x265amd_field_me_multi_tmvp)"""
         enc = np.ascontiguousarray(enc_planes, dtype=np.int32)
         ref = np.ascontiguousarray(ref_planes, dtype=np.int32)
         pw = np.ascontiguousarray(pu_w, dtype=np.int32)
@@ -341,9 +344,14 @@ class Engine:
         n = sum(gw * gh for gw, gh in grids)
         out = np.zeros(n, dtype=RESULT_DTYPE) if fetch else None
         mvp = np.zeros((n, 2), dtype=np.int16) if fetch else None
-        self._chk(self.lib.x265amd_field_me_multi(self.h, len(enc), enc.ctypes.data, ref.ctypes.data, pw.ctypes.data, ph.ctypes.data,
-                                                  pm.ctypes.data, merange, method, subme, qp,
-                                                  out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
+        if col is not None:
+            col = np.ascontiguousarray(col, dtype=RESULT_DTYPE)
+            if col.size != len(enc) * ((w + 15) // 16) * ((h + 15) // 16):
+                raise ValueError("col needs one entry per 16x16 block of the picture and field")
+        self._chk(self.lib.x265amd_field_me_multi_tmvp(self.h, len(enc), enc.ctypes.data, ref.ctypes.data, pw.ctypes.data, ph.ctypes.data,
+                                                       pm.ctypes.data, col.ctypes.data if col is not None else None,
+                                                       merange, method, subme, qp,
+                                                       out.ctypes.data if fetch else None, mvp.ctypes.data if fetch else None))
         if not fetch:
             return None
         res, at = [], 0

@@ -12,8 +12,10 @@
 // Per PU at grid position (gx, gy), with the final MVs of its left / above / above-right / above-left
 // neighbours:
 //   * candidate A = left MV; candidate B = the first that exists of above-right, above, above-left
-//     (the spatial AMVP scan order of HEVC); B is dropped when equal to A; the list is padded with zero
-//     vectors to AMVP_MAX_NUM_CANDS = 2 (Lib/TLibCommon/CommonDef.h:161).  No temporal candidate.
+//     (the spatial AMVP scan order of HEVC); B is dropped when equal to A; with a co-located motion field (`col`, one
+//     entry per 16x16 block, scaled by the caller to this reference distance, cost < 0 = none) the temporal candidate
+//     follows while the list holds fewer than two; the list is padded with zero vectors to AMVP_MAX_NUM_CANDS = 2
+//     (Lib/TLibCommon/CommonDef.h:161).
 //   * mvp = the candidate with the smaller template cost = SAD of the source PU against the
 //     motion-compensated block at the candidate clipped by TComDataCU::clipMv
 //     (Lib/TLibCommon/TComDataCU.cpp:2724-2736); xPredInterLumaBlk (TComPrediction.cpp:464-496) is the
@@ -55,7 +57,8 @@ template <class L>
 __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
                                                  int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
                                                  int merange, int method, int subme, int qp, int flags, int part_mode,
-                                                 x265amd_me_result *out, int *out_mvp, int *error, unsigned long long *evals)
+                                                 const x265amd_me_result *col, x265amd_me_result *out, int *out_mvp, int *error,
+                                                 unsigned long long *evals)
 {
     __shared__ __align__(16) L lds;
     // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU (CU) rows of field f, top row first
@@ -66,6 +69,9 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
     const int cut_h = part_mode == 4 ? pu_h >> 2 : pu_h - (pu_h >> 2), cut_w = part_mode == 6 ? pu_w >> 2 : pu_w - (pu_w >> 2);
     out += (size_t)field * gw * gh * parts;
     out_mvp += (size_t)field * gw * gh * parts;
+    const int col_w = (pic_w + 15) >> 4;                                 // 16x16 blocks per row of the co-located motion
+    if (col)
+        col += (size_t)field * col_w * ((pic_h + 15) >> 4);
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
     {
         Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
@@ -123,18 +129,43 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         const int wa_cand = parts == 2 ? last[1] : left;                // candidate A: 2NxN upper part - below-left, else left
         const int wb = have_ar ? w_ar : have_a ? w_a : w_al;
         const bool have_b = have_a;                                     // (above exists whenever any of the three does)
-        int c0x = 0, c0y = 0, c1x = 0, c1y = 0;
+        int c0x = 0, c0y = 0, c1x = 0, c1y = 0, n_cand = 0;
         if (have_l)
         {
             c0x = mvx(wa_cand); c0y = mvy(wa_cand);
+            n_cand = 1;
             if (have_b && wb != wa_cand)
             {
                 c1x = mvx(wb); c1y = mvy(wb);
+                n_cand = 2;
             }
         }
         else if (have_b)
         {
             c0x = mvx(wb); c0y = mvy(wb);
+            n_cand = 1;
+        }
+        if (col && n_cand < 2)
+        {
+            // The temporal candidate (fillMvpCand, TComDataCU.cpp:2635-2697): the co-located motion below-right of the PU unless that
+            // lies outside the picture or in the next CTU row, else - also when that block has none - at the PU's centre
+            // (xDeriveCenterIdx, :3104-3116); motion is kept per 16x16 block (xGetColMVP masks the address, :3010).  It goes in
+            // unpruned and the list is cut to two (:2699-2702), so it counts only while there is room.
+            const int rbx = px + bw, rby = py + bh;
+            const int ctx = px + ((bw >> 3) << 2), cty = py + ((bh >> 3) << 2);
+            const bool rb_ok = rbx < pic_w && rby < pic_h && (rby & (max_cu - 1)) != 0;
+            x265amd_me_result t = col[(cty >> 4) * col_w + (ctx >> 4)];
+            if (rb_ok)
+            {
+                const x265amd_me_result rb = col[(rby >> 4) * col_w + (rbx >> 4)];
+                if (rb.cost >= 0)
+                    t = rb;
+            }
+            if (t.cost >= 0)
+            {
+                if (n_cand == 0) { c0x = t.mvx; c0y = t.mvy; }
+                else             { c1x = t.mvx; c1y = t.mvy; }
+            }
         }
         // TComDataCU::clipMv for a CU at (cux, cuy)
         const int xmax = (pic_w + 8 - cux - 1) << 2, xmin = (-max_cu - 8 - cux + 1) << 2;

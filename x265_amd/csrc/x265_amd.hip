@@ -105,7 +105,7 @@ struct x265amd_ctx
     unsigned long long *d_evals = nullptr;   // EVAL_SLOTS counters 16 words apart (+ 16 words of developer counters)
 
     DevBuf jobs, results, fullbest, pairs, costs, stage, items, item_jobs, look_pairs, look_results, look_progress, plan_mem;
-    DevBuf field_results, field_mvp;
+    DevBuf field_results, field_mvp, field_col;
     void  *h_stage = nullptr;             // pinned staging for the per-call primitives
     size_t h_stage_cap = 0;
     // Largest PU of a FULL job with an exhaustive-kernel scan that the row-per-job kernel takes (X265AMD_LANE_FULL, up to
@@ -1604,7 +1604,7 @@ void x265amd_destroy(x265amd_ctx *c)
         c->batch_list = nullptr;
     }
     DevBuf *bufs[] = { &c->jobs, &c->results, &c->fullbest, &c->pairs, &c->costs, &c->stage, &c->items, &c->item_jobs, &c->plan_mem,
-                       &c->look_pairs, &c->look_results, &c->look_progress, &c->field_results, &c->field_mvp };
+                       &c->look_pairs, &c->look_results, &c->look_progress, &c->field_results, &c->field_mvp, &c->field_col };
     for (DevBuf *b : bufs)
         if (b->p)
             hipFree(b->p);
@@ -2127,11 +2127,12 @@ extern "C++" {
 namespace {
 template <typename PIX>
 void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_fields, int gh, const uint16_t *cost, const LookPair *pairs, int pu_w, int pu_h,
-                  int gw, int pic_w, int pic_h, int merange, int method, int subme, int qp, int part_mode, x265amd_me_result *res, int *mvp, int *error)
+                  int gw, int pic_w, int pic_h, int merange, int method, int subme, int qp, int part_mode, const x265amd_me_result *col,
+                  x265amd_me_result *res, int *mvp, int *error)
 {
 #define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_fields * gh), dim3(NW * 64), 0, st, c->d_planes, cost, \
                                               pairs, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags, part_mode,   \
-                                              res, mvp, error, c->d_evals)
+                                              col, res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
     else if (cls == 1) XA_FIELD(4, 256);
     else               XA_FIELD(8, 1024);
@@ -2155,6 +2156,14 @@ bool field_two_rows(int part_mode) { return part_mode == 1 || part_mode == 4 || 
 
 int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w, const int *pu_h,
                            const int *part_mode, int merange, int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp)
+{
+    return x265amd_field_me_multi_tmvp(c, n_fields, enc_planes, ref_planes, pu_w, pu_h, part_mode, nullptr, merange, method, subme, qp, out,
+                                       out_mvp);
+}
+
+int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_planes, const int *ref_planes, const int *pu_w, const int *pu_h,
+                                const int *part_mode, const x265amd_me_result *col, int merange, int method, int subme, int qp,
+                                x265amd_me_result *out, int16_t *out_mvp)
 {
     if (!c || n_fields < 1 || n_fields > 4096 || !enc_planes || !ref_planes || !pu_w || !pu_h)
         return X265AMD_ERR_INVALID;
@@ -2196,6 +2205,13 @@ int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, 
     if (int rc = ensure_error_words(c)) return rc;
     if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
+    // the co-located motion: one grid of 16x16 blocks per field (the caller's array may die after the call)
+    const size_t col_per = (size_t)((e.width + 15) >> 4) * ((e.height + 15) >> 4);
+    if (col)
+    {
+        if (int rc = ensure(c, c->field_col, col_per * n_fields * sizeof(x265amd_me_result))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->field_col.p, col, col_per * n_fields * sizeof(x265amd_me_result), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));      // hp dies here
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->field_results.p, LOOK_UNSET, n * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
@@ -2263,10 +2279,11 @@ int x265amd_field_me_multi(x265amd_ctx *c, int n_fields, const int *enc_planes, 
         int *mvp = (int*)c->field_mvp.p + first[f0];
         const LookPair *pairs = (const LookPair*)c->look_pairs.p + f0;
         int *err = (int*)c->look_progress.p + ERR_WORD_FIELD;
+        const x265amd_me_result *dcol = col ? (const x265amd_me_result*)c->field_col.p + col_per * f0 : nullptr;
         if (e.bpp == 1)
-            launch_field<uint8_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, res, mvp, err);
+            launch_field<uint8_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, dcol, res, mvp, err);
         else
-            launch_field<uint16_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, res, mvp, err);
+            launch_field<uint16_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, dcol, res, mvp, err);
         HIPCHK(c, hipGetLastError());
     }
     for (int i = 0; i + 1 < n_streams; i++)

@@ -135,6 +135,22 @@ inline void setSearchRange(MV mvp, int merange, int picW, int picH, int cuX, int
     mvmax = clipMv(MV((int16_t)(c.x + d), (int16_t)(c.y + d)), picW, picH, cuX, cuY) >> 2;
 }
 
+// The scaling xGetColMVP applies to a co-located MV (Lib/TLibCommon/TComDataCU.cpp:3047-3075: xGetDistScaleFactor :3079-3096,
+// scaleMv :45-51): what a caller runs over a coded picture's motion, one MV per 16x16 block, before handing it to
+// x265amd_field_me_multi_tmvp as the source of the temporal AMVP candidate.
+inline MV scaleColMv(MV mv, int curPOC, int curRefPOC, int colPOC, int colRefPOC)
+{
+    const int d = colPOC - colRefPOC, b = curPOC - curRefPOC;
+    if (d == b)
+        return mv;
+    const int tdb = b < -128 ? -128 : b > 127 ? 127 : b, tdd = d < -128 ? -128 : d > 127 ? 127 : d;
+    const int x = (0x4000 + (tdd / 2 < 0 ? -(tdd / 2) : tdd / 2)) / tdd;
+    int scale = (tdb * x + 32) >> 6;
+    scale = scale < -4096 ? -4096 : scale > 4095 ? 4095 : scale;
+    const int vx = (scale * mv.x + 127 + (scale * mv.x < 0)) >> 8, vy = (scale * mv.y + 127 + (scale * mv.y < 0)) >> 8;
+    return MV((int16_t)(vx < -32768 ? -32768 : vx > 32767 ? 32767 : vx), (int16_t)(vy < -32768 ? -32768 : vy > 32767 ? 32767 : vy));
+}
+
 // A motion field computed AHEAD of the CU analysis: the searches TEncSearch::predInterSearch is
 // expected to ask for (Lib/TLibEncoder/TEncSearch.cpp:2392-2451: one motionEstimate per PU, list and
 // reference, with a predictor the caller can often foresee, e.g. from the lookahead's half-resolution
@@ -268,8 +284,10 @@ public:
         }
         return r;
     }
+    // col (optional): the co-located motion for the temporal AMVP candidate, per shape one grid of ((width + 15) / 16) x
+    // ((height + 15) / 16) entries (one per 16x16 block, scaled with scaleColMv, cost < 0 = no motion), one grid after the other.
     void runChained(const ReferencePlanes &enc, const ReferencePlanes &ref, const std::vector<Shape> &shapes, int merange, int method,
-                    int subme, int qp)
+                    int subme, int qp, const std::vector<x265amd_me_result> *col = nullptr)
     {
         const int nf = (int)shapes.size();
         std::vector<int> encs(nf, enc.plane_id), refids(nf, ref.plane_id), pw(nf), ph(nf), pm(nf);
@@ -283,8 +301,10 @@ public:
         }
         std::vector<x265amd_me_result> all(first[nf]);
         std::vector<int16_t> allmvp(first[nf] * 2);
-        m_ctx.check(x265amd_field_me_multi(m_ctx.get(), nf, encs.data(), refids.data(), pw.data(), ph.data(), pm.data(), merange, method,
-                                           subme, qp, all.data(), allmvp.data()));
+        if (col && col->size() != (size_t)nf * ((enc.width + 15) / 16) * ((enc.height + 15) / 16))
+            throw std::invalid_argument("runChained: col needs one entry per 16x16 block and shape");
+        m_ctx.check(x265amd_field_me_multi_tmvp(m_ctx.get(), nf, encs.data(), refids.data(), pw.data(), ph.data(), pm.data(),
+                                                col ? col->data() : nullptr, merange, method, subme, qp, all.data(), allmvp.data()));
         if (m_valid && m_enc != enc.plane_id)
             clear();
         for (int f = 0; f < nf; f++)
