@@ -20,7 +20,7 @@ def test_adapter_header_compiles():
 def test_adapter_results_match_oracle(oracle, tmp_path):
     from x265_amd import jobs as J, synth
     assert os.path.exists(DEMO), "build it with __graft_entry__.build()"
-    W, H, M = 256, 128, synth.MARGIN
+    W, H, M = 512, 256, synth.MARGIN
     fr = synth.make_sequence(W, H, 2, seed=404)
     e, r = str(tmp_path / "enc.raw"), str(tmp_path / "ref.raw")
     fr[0].tofile(e)
@@ -141,4 +141,4 @@ def test_adapter_results_match_oracle(oracle, tmp_path):
         elif not seen_intra.get(key):
             assert l[22] == "1", l
     st = [int(v) for v in [l for l in lines if l[0] == "mchainstats"][0][1:]]
-    assert st[0] + st[1] == st[2] == n_exp and st[0] >= 0.85 * st[2], st
+    assert st[0] + st[1] == st[2] == n_exp and st[0] >= 0.9 * st[2], st

@@ -1,7 +1,7 @@
 import os, subprocess, sys
 sys.path.insert(0, os.getcwd())
 from x265_amd import synth
-W, H, M = 256, 128, synth.MARGIN
+W, H, M = 512, 256, synth.MARGIN
 fr = synth.make_sequence(W, H, 2, seed=404)
 fr[0].tofile("/tmp/enc.raw"); fr[1].tofile("/tmp/ref.raw")
 out = subprocess.run(["tests/cpp/adapter_demo", str(W), str(H), str(M), "/tmp/enc.raw", "/tmp/ref.raw"], capture_output=True, text=True, timeout=100)
