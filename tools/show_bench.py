@@ -3,8 +3,8 @@
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
 r = d["roofline"]
-print("value %.4g %s  ms_per_step %.4f  exhaustive kernels %.4f ms (frac %.3f, executed %.3f)  tail %.4f ms  parity %s" %
-      (d["value"], d["unit"], d["ms_per_step"], r["kernel_ms"], r["frac"], r.get("executed_frac", 0), r.get("search_kernel_ms", 0),
+print("value %.4g %s  ms_per_step %.4f  exhaustive kernels %.4f ms (frac %.3f, with frames in flight %.3f)  tail %.4f ms  parity %s" %
+      (d["value"], d["unit"], d["ms_per_step"], r["kernel_ms"], r["frac"], r.get("frames_in_flight_frac", 0), r.get("search_kernel_ms", 0),
        d.get("parity_sample_ok")))
 if "hex_search" in d:
     h = d["hex_search"]

@@ -31,17 +31,16 @@ def single_rank_group(device=None) -> str:
     multi-GPU path really run on a single GPU; returns the backend name.  Does nothing if a group exists."""
     if dist.is_initialized():
         return dist.get_backend()
-    import os
-    port = 29700 + (os.getpid() % 200)
     last = None
     for backend in (("nccl", "gloo") if device is not None else ("gloo",)):
         try:
             kw = {"device_id": device} if backend == "nccl" else {}
-            dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+            # (an in-process store: no port, and nothing a launcher put into the environment - its rendezvous store, say - is
+            # consulted; a tcp:// rendezvous under torch.distributed.run would wait as a client for a store nobody started)
+            dist.init_process_group(backend, store=dist.HashStore(), rank=0, world_size=1, **kw)
             return backend
         except Exception as e:      # pragma: no cover - depends on the box
             last = e
-            port += 1
     raise last
 
 
