@@ -290,8 +290,8 @@ int x265amd_joblist_run(x265amd_ctx *ctx, x265amd_joblist *list, int enc_plane, 
  * uses; set 1 = the other two; sets 2 and 3 = those pairs with main and side stream exchanged; sets 4 .. 7 = the main
  * stream of set 0 .. 3 alone (the launches of one batch then follow each other instead of running side by side).
  * Runs queued on different sets execute side by side, so the workgroups of one frame's search fill the compute units
- * that the end of another frame's kernels leaves idle (MI355X, 1080p: exhaustive frames 0.514 ms one at a time, 0.446
- * on sets 0 / 1 in turn, 0.42 on sets 4 .. 7 in turn; HEX + subme 5 frames 0.153 -> 0.098 on sets 0 / 1).  Each frame
+ * that the end of another frame's kernels leaves idle (MI355X, 1080p: exhaustive frames 0.50 ms one at a time, 0.43
+ * on sets 0 / 1 in turn, 0.405 on sets 4 .. 7 in turn; HEX + subme 5 frames 0.153 -> 0.098 on sets 0 / 1).  Each frame
  * in flight needs its own list (a list's next run, on any set, starts behind its last one).  x265amd_sync waits for all
  * sets; x265amd_joblist_results / _results_async / _eval_counts wait for the list's last run wherever it ran; a pointer
  * from x265amd_joblist_results_device is valid after x265amd_sync.  The kernel times of x265amd_set_timing are those of
