@@ -385,8 +385,10 @@ int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes
                            int merange, int method, int subme, int qp, x265amd_me_result *out, int16_t *out_mvp);
 /* The same with a PU size and a partition mode PER FIELD, e.g. one field per quadtree depth of a frame, or the 2NxN and
  * Nx2N fields beside the 2Nx2N one (the PartSize loop around predInterSearch in TEncCu::xCompressCU, Lib/TLibEncoder/TEncCu.cpp).
- * Consecutive fields of one size and mode share a launch; the launches run side by side on different streams, so the call takes
- * about as long as its longest chain (the smallest PUs).
+ * All fields of a call are in flight side by side - fields whose PUs fall into one kernel class (at most 256 / 1024 / 4096 pixels)
+ * share a launch whatever their size and mode, and the up to three launches run on different streams - so the call takes about as
+ * long as its longest chain (MI355X, 1080p: the twenty fields of the four square sizes, the 2NxN / Nx2N parts of 16 and 32 and all
+ * asymmetric parts of 16, 32 and 64 in one call 11.2 ms; the slowest of them alone, 16x8 parts, 10.7 ms).
  *   part_mode[f] (NULL: all 0) = 0: 2Nx2N - every PU is its own CU;
  *                                1: 2NxN - CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 are their upper / lower parts;
  *                                2: Nx2N - CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts;

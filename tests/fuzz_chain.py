@@ -43,7 +43,7 @@ def main():
     rng = np.random.default_rng(seed)
     eng, oracle = Engine(0), Oracle()
     t0 = time.time()
-    n_look = n_field = cus = pus = 0
+    n_look = n_field = n_calls = cus = pus = 0
     while time.time() - t0 < budget:
         bits = int(rng.choice([8, 16]))
         depth = 8 if bits == 8 else 10
@@ -74,49 +74,60 @@ def main():
             cus += 2 * g.cu_w * g.cu_h
             what = "lookahead %4dx%-4d" % (w, h)
         else:
-            # ---- predictor-chained field of one PU size and partition mode (0 2Nx2N, 1 2NxN, 2 Nx2N, 4..7 the asymmetric ones)
-            pm = int(rng.choice([0, 0, 1, 2, 4, 5, 6, 7]))
-            if pm >= 4:
-                pw = ph = int(rng.choice([16, 32, 64]))
-            elif pm:
-                pw, ph = [(16, 8), (32, 16), (64, 32), (8, 4), (16, 16), (8, 8)][int(rng.integers(0, 6))]
-                if pm == 2:
-                    pw, ph = ph, pw
-            else:
-                pw, ph = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)][int(rng.integers(0, 7))]
-            w, h = 8 * int(rng.integers(max(2, pw // 8 * 2), 60)), 8 * int(rng.integers(max(2, ph // 8 * 2), 36))
+            # ---- predictor-chained fields, one to four in one call, each with its own PU size and partition mode
+            #      (0 2Nx2N, 1 2NxN, 2 Nx2N, 4..7 the asymmetric ones) and, for half of the calls, co-located motion
+            def draw_shape():
+                pm = int(rng.choice([0, 0, 1, 2, 4, 5, 6, 7]))
+                if pm >= 4:
+                    pw = ph = int(rng.choice([16, 32, 64]))
+                elif pm:
+                    pw, ph = [(16, 8), (32, 16), (64, 32), (8, 4), (16, 16), (8, 8)][int(rng.integers(0, 6))]
+                    if pm == 2:
+                        pw, ph = ph, pw
+                else:
+                    pw, ph = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)][int(rng.integers(0, 7))]
+                return pw, ph, pm
+            shapes = [draw_shape() for _ in range(int(rng.choice([1, 1, 2, 3, 4])))]
+            cu_w = max(pw * (2 if pm == 2 else 1) for pw, ph, pm in shapes)
+            cu_h = max(ph * (2 if pm == 1 else 1) for pw, ph, pm in shapes)
+            w, h = 8 * int(rng.integers(max(2, cu_w // 8), 60)), 8 * int(rng.integers(max(2, cu_h // 8), 36))
             fr = make_frames(rng, w, h, depth, kind)
             method, subme = int(rng.integers(0, 5)), int(rng.integers(0, 8))
             merange, qp = int(rng.choice([8, 16, 32, 57])), int(rng.integers(10, 45))
             if method == 4:
                 merange = 8
             ids = [eng.upload_plane(f, bit_depth=depth) for f in fr]
-            if method == 2 and pw * ph == 16:       # (UMH has no 4x4)
-                method = 1
-            col = None
-            if rng.random() < 0.5:                  # a co-located motion field for the temporal candidate
+            cols = None
+            if rng.random() < 0.5:                  # co-located motion fields for the temporal candidate, one per field
                 from x265_amd.jobs import RESULT_DTYPE
                 nb = ((w + 15) // 16) * ((h + 15) // 16)
-                col = np.zeros(nb, dtype=RESULT_DTYPE)
-                spread = int(rng.choice([3, 12, 60]))
-                col["mvx"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
-                col["mvy"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
-                col["cost"] = np.where(rng.random(nb) < rng.choice([0.0, 0.2, 0.7]), -1, 0)
-            got, got_mvp = eng.field_me_multi([ids[1]], [ids[0]], [pw], [ph], [pm], merange, method, subme, qp, col=col)[0]
-            exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth, part_mode=pm, col=col)
-            if not (np.array_equal(got, exp) and np.array_equal(got_mvp, exp_mvp)):
-                print("MISMATCH field (col %s) %dx%d PU %dx%d mode %d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
-                      % (col is not None, w, h, pw, ph, pm, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
-                sys.exit(1)
+                cols = np.zeros((len(shapes), nb), dtype=RESULT_DTYPE)
+                for col in cols:
+                    spread = int(rng.choice([3, 12, 60]))
+                    col["mvx"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
+                    col["mvy"] = rng.integers(-spread, spread + 1, nb) + int(rng.integers(-20, 21))
+                    col["cost"] = np.where(rng.random(nb) < rng.choice([0.0, 0.2, 0.7]), -1, 0)
+            n = len(shapes)
+            got_all = eng.field_me_multi([ids[1]] * n, [ids[0]] * n, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes],
+                                         merange, method, subme, qp, col=cols)
+            for k, (pw, ph, pm) in enumerate(shapes):
+                col = cols[k] if cols is not None else None
+                exp, exp_mvp, _ = oracle.field_me(fr[1], fr[0], pw, ph, merange, method, subme, qp, bit_depth=depth, part_mode=pm, col=col)
+                got, got_mvp = got_all[k]
+                if not (np.array_equal(got, exp) and np.array_equal(got_mvp, exp_mvp)):
+                    print("MISMATCH field %d of %s (col %s) %dx%d bits %d depth %d %s method %d subme %d merange %d qp %d: PUs %s"
+                          % (k, shapes, col is not None, w, h, bits, depth, kind, method, subme, merange, qp, np.argwhere(got != exp)[:5]), flush=True)
+                    sys.exit(1)
+                n_field += 1
+                pus += got.size
             for p in ids:
                 eng.release_plane(p)
-            n_field += 1
-            pus += got.size
-            what = "field %4dx%-4d PU %2dx%-2d mode %d%s" % (w, h, pw, ph, pm, " +col" if col is not None else "")
-        if (n_look + n_field) % 20 == 0:
-            print("case %d ok: %s %2d-bit depth %2d %-6s (%d s)" % (n_look + n_field, what, bits, depth, kind, time.time() - t0), flush=True)
-    print("chained-path campaign: %d lookahead cases (%d CU searches) and %d chained fields (%d PU searches), all bit-exact against "
-          "the oracle (seed %d, %.0f s)" % (n_look, cus, n_field, pus, seed, time.time() - t0), flush=True)
+            n_calls += 1
+            what = "fields %4dx%-4d %s%s" % (w, h, shapes, " +col" if cols is not None else "")
+        if (n_look + n_calls) % 20 == 0:
+            print("case %d ok: %s %2d-bit depth %2d %-6s (%d s)" % (n_look + n_calls, what, bits, depth, kind, time.time() - t0), flush=True)
+    print("chained-path campaign: %d lookahead cases (%d CU searches) and %d chained fields in %d calls (%d PU searches), all bit-exact "
+          "against the oracle (seed %d, %.0f s)" % (n_look, cus, n_field, n_calls, pus, seed, time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":

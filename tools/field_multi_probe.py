@@ -26,3 +26,6 @@ for s in shapes:
 print("squares together: %.2f ms" % run(shapes[:4]))
 print("8x8 + 16x16: %.2f ms" % run(shapes[:2]))
 print("all eight: %.2f ms" % run(shapes))
+amp = [(c, c, m) for c in (16, 32, 64) for m in (4, 5, 6, 7)]
+print("twelve asymmetric fields (16 / 32 / 64 x modes 4..7): %.2f ms" % run(amp))
+print("all twenty: %.2f ms" % run(shapes + amp))

@@ -51,34 +51,52 @@ namespace xa {
 // CU, cut a quarter (4, 6) or three quarters (5, 7) of the way down / across; PU sizes and corner positions are those of
 // deriveLeftRightTopIdxGeneral / deriveLeftBottomIdxGeneral (TComDataCU.cpp:1837-1944).  The cut moves, the CUs that the corner
 // positions fall into do not: the neighbours of the two parts are those of mode 1 (4, 5) / mode 2 (6, 7).
-// With upper / lower parts (modes 1, 4, 5) one workgroup owns a CU row (two PU rows, walked upper part, lower part, next CU) and
-// `gh` counts CU rows.
+// With upper / lower parts (modes 1, 4, 5) one workgroup owns a CU row (two PU rows, walked upper part, lower part, next CU).
+// One field of a launch.  The fields of a launch may differ in PU size, partition mode and planes (they share the kernel class,
+// i.e. the range of PU areas); workgroups [first_wg, first_wg + wg_rows) are the PU (CU) rows of the field, top row first, so a
+// row's predecessor always has the lower workgroup index and is dispatched before it.
+struct FieldDesc
+{
+    int32_t enc_plane, ref_plane;
+    int32_t pu_w, pu_h, gw, wg_rows, part_mode;
+    int32_t first_wg;          // first workgroup of the field in its launch
+    int32_t first_out;         // first result / predictor of the field in the call's output arrays
+    int32_t first_col;         // first entry of the field's co-located motion, -1: none
+};
+
 template <class L>
-__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const LookPair *pairs,
-                                                 int pu_w, int pu_h, int gw, int gh, int pic_w, int pic_h, int max_cu,
-                                                 int merange, int method, int subme, int qp, int flags, int part_mode,
+__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const FieldDesc *fields, int n_fields,
+                                                 int pic_w, int pic_h, int max_cu, int merange, int method, int subme, int qp, int flags,
                                                  const x265amd_me_result *col, x265amd_me_result *out, int *out_mvp, int *error,
                                                  unsigned long long *evals)
 {
     __shared__ __align__(16) L lds;
-    // several fields per launch: workgroups [f * gh, (f + 1) * gh) are the PU (CU) rows of field f, top row first
-    const int field = (int)blockIdx.x / gh, row = (int)blockIdx.x - field * gh;
+    // the field of this workgroup: the last one that starts at or before it
+    int lo = 0, hi = n_fields - 1;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi + 1) >> 1;
+        if (fields[mid].first_wg <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const FieldDesc F = fields[lo];
+    const int pu_w = F.pu_w, pu_h = F.pu_h, gw = F.gw, part_mode = F.part_mode;
+    const int row = (int)blockIdx.x - F.first_wg;
     const bool amp = part_mode >= 4;
     const bool horiz = part_mode == 1 || part_mode == 4 || part_mode == 5, vert = part_mode == 2 || part_mode == 6 || part_mode == 7;
     const int parts = horiz ? 2 : 1;                                     // PU rows per workgroup
     const int cut_h = part_mode == 4 ? pu_h >> 2 : pu_h - (pu_h >> 2), cut_w = part_mode == 6 ? pu_w >> 2 : pu_w - (pu_w >> 2);
-    out += (size_t)field * gw * gh * parts;
-    out_mvp += (size_t)field * gw * gh * parts;
+    out += F.first_out;
+    if (out_mvp)
+        out_mvp += F.first_out;
     const int col_w = (pic_w + 15) >> 4;                                 // 16x16 blocks per row of the co-located motion
-    if (col)
-        col += (size_t)field * col_w * ((pic_h + 15) >> 4);
+    col = F.first_col >= 0 ? col + F.first_col : nullptr;
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
     {
         Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
         return;
     }
-    const PlaneDesc &enc = planes[pairs[field].enc_plane];
-    const PlaneDesc &ref = planes[pairs[field].ref_plane];
+    const PlaneDesc &enc = planes[F.enc_plane];
+    const PlaneDesc &ref = planes[F.ref_plane];
     unsigned n_evals = 0;
     int failed = 0;
     int last[2] = { 0, 0 };                                              // MV word of the PU to the left, per PU row of the workgroup

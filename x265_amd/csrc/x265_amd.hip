@@ -2126,12 +2126,12 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
 extern "C++" {
 namespace {
 template <typename PIX>
-void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_fields, int gh, const uint16_t *cost, const LookPair *pairs, int pu_w, int pu_h,
-                  int gw, int pic_w, int pic_h, int merange, int method, int subme, int qp, int part_mode, const x265amd_me_result *col,
+void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_wgs, const uint16_t *cost, const FieldDesc *fields, int n_fields,
+                  int pic_w, int pic_h, int merange, int method, int subme, int qp, const x265amd_me_result *col,
                   x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_fields * gh), dim3(NW * 64), 0, st, c->d_planes, cost, \
-                                              pairs, pu_w, pu_h, gw, gh, pic_w, pic_h, 64, merange, method, subme, qp, c->flags, part_mode,   \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_wgs), dim3(NW * 64), 0, st, c->d_planes, cost, \
+                                              fields, n_fields, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               col, res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
     else if (cls == 1) XA_FIELD(4, 256);
@@ -2171,7 +2171,6 @@ int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_pla
     HIPCHK(c, hipSetDevice(c->device));
     if (method < X265AMD_DIA || method > X265AMD_FULL || subme < 0 || subme > 7 || qp < 0 || qp > 51 || merange < 0 || merange > 32767)
         return fail(c, X265AMD_ERR_INVALID, "field search parameter out of range");
-    std::vector<LookPair> hp(n_fields);
     std::vector<size_t> first(n_fields + 1, 0);         // first result of field f
     for (int f = 0; f < n_fields; f++)
     {
@@ -2190,8 +2189,6 @@ int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_pla
         // clipMv lets a block reach 64 + 8 - 1 pixels beyond the picture; plus pattern overshoot and the filter apron
         if (r.margin_x < 71 + 3 + 4 || r.margin_y < 71 + 3 + 4)
             return fail(c, X265AMD_ERR_RANGE, "reference margins below 78 pixels");
-        hp[f].enc_plane = enc_planes[f];
-        hp[f].ref_plane = ref_planes[f];
         int gw, gh;
         if (!field_grid(ef.width, ef.height, pu_w[f], pu_h[f], pm, gw, gh))
             return fail(c, X265AMD_ERR_INVALID, "picture smaller than one CU");
@@ -2203,87 +2200,95 @@ int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_pla
     if (int rc = ensure(c, c->field_results, n * sizeof(x265amd_me_result))) return rc;
     if (int rc = ensure(c, c->field_mvp, n * sizeof(int))) return rc;
     if (int rc = ensure_error_words(c)) return rc;
-    if (int rc = ensure(c, c->look_pairs, hp.size() * sizeof(LookPair))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, hp.data(), hp.size() * sizeof(LookPair), hipMemcpyHostToDevice, c->stream));
-    // the co-located motion: one grid of 16x16 blocks per field (the caller's array may die after the call)
+    // One launch per kernel class (PUs of at most 256 / 1024 / 4096 pixels; the larger part of an asymmetric CU, three quarters of
+    // it, decides): fields of different PU sizes and partition modes share a launch through their descriptors.  A field's time is
+    // the length of its chain, not its work, so all fields of the call are in flight side by side, the launches on different
+    // streams; inside a launch the longest chains come first (a chain's length in PU steps is a row's PUs plus the two-CU lag of
+    // every further row, and a step takes about 12 + 0.75 sqrt(PU area) microseconds - measured 16 us at 8x8, 24 at 16x16, 39 at
+    // 32x32, 62 at 64x64).
     const size_t col_per = (size_t)((e.width + 15) >> 4) * ((e.height + 15) >> 4);
+    std::vector<FieldDesc> desc[3];
+    std::vector<double> len(n_fields);
+    for (int cls = 0; cls < 3; cls++)
+    {
+        std::vector<int> of_cls;
+        for (int f = 0; f < n_fields; f++)
+        {
+            const int pm = part_mode ? part_mode[f] : 0;
+            if ((pm >= 4 ? job_class(pu_w[f], pu_h[f] - (pu_h[f] >> 2)) : job_class(pu_w[f], pu_h[f])) != cls)
+                continue;
+            int gw, gh;
+            field_grid(e.width, e.height, pu_w[f], pu_h[f], pm, gw, gh);
+            const int parts = field_two_rows(pm) ? 2 : 1;
+            // (the two parts of an asymmetric CU together have the CU's area: half of it each on average)
+            const double area = (double)pu_w[f] * pu_h[f] * (pm >= 4 ? 0.5 : 1.0);
+            len[f] = parts * (gw + 2 * (gh / parts)) * (12.0 + 0.75 * sqrt(area));
+            of_cls.push_back(f);
+        }
+        std::stable_sort(of_cls.begin(), of_cls.end(), [&](int a, int b) { return len[a] > len[b]; });
+        int wg = 0;
+        for (int f : of_cls)
+        {
+            const int pm = part_mode ? part_mode[f] : 0;
+            int gw, gh;
+            field_grid(e.width, e.height, pu_w[f], pu_h[f], pm, gw, gh);
+            FieldDesc d;
+            d.enc_plane = enc_planes[f]; d.ref_plane = ref_planes[f];
+            d.pu_w = pu_w[f]; d.pu_h = pu_h[f]; d.gw = gw; d.wg_rows = field_two_rows(pm) ? gh / 2 : gh; d.part_mode = pm;
+            d.first_wg = wg; d.first_out = (int32_t)first[f]; d.first_col = col ? (int32_t)(col_per * f) : -1;
+            wg += d.wg_rows;
+            desc[cls].push_back(d);
+        }
+    }
+    std::vector<FieldDesc> all_desc;
+    size_t desc_at[3];
+    int n_launch = 0;
+    for (int cls = 0; cls < 3; cls++)
+    {
+        desc_at[cls] = all_desc.size();
+        all_desc.insert(all_desc.end(), desc[cls].begin(), desc[cls].end());
+        n_launch += desc[cls].empty() ? 0 : 1;
+    }
+    if (int rc = ensure(c, c->look_pairs, all_desc.size() * sizeof(FieldDesc))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->look_pairs.p, all_desc.data(), all_desc.size() * sizeof(FieldDesc), hipMemcpyHostToDevice, c->stream));
+    // the co-located motion: one grid of 16x16 blocks per field (the caller's array may die after the call)
     if (col)
     {
         if (int rc = ensure(c, c->field_col, col_per * n_fields * sizeof(x265amd_me_result))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->field_col.p, col, col_per * n_fields * sizeof(x265amd_me_result), hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // hp dies here
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the descriptors die here
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->field_results.p, LOOK_UNSET, n * 2, c->stream));   // "not searched yet"
     if (int rc = record_start(c)) return rc;
     if (c->timing)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint16_t *cost = c->d_cost + (size_t)qp * 65536 + 32768;
-    // One launch per run of consecutive fields of one PU size and partition mode.  A field's time is the length of its chain, not
-    // its work, so the launches go to different streams and run side by side.
-    struct Run { int f0, f1; };
-    std::vector<Run> runs;
-    for (int f = 0; f < n_fields; f++)
-    {
-        const int pm = part_mode ? part_mode[f] : 0;
-        if (!runs.empty())
-        {
-            const int p = runs.back().f0;
-            if (pu_w[p] == pu_w[f] && pu_h[p] == pu_h[f] && (part_mode ? part_mode[p] : 0) == pm)
-            {
-                runs.back().f1 = f + 1;
-                continue;
-            }
-        }
-        runs.push_back({ f, f + 1 });
-    }
-    const int n_streams = (int)std::min<size_t>(runs.size(), x265amd_ctx::N_AUX + 1);
+    const int n_streams = n_launch;
     if (n_streams > 1)
     {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int i = 0; i + 1 < n_streams; i++)
             HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
     }
-    // (launches on one stream run one after the other: the runs go, longest chain first, to the stream with the least queued;
-    // a chain's length in PU steps is a row's PUs plus the two-CU lag of every further row, and a step takes about
-    // 12 + 0.75 sqrt(PU area) microseconds - measured 16 us at 8x8, 24 at 16x16, 39 at 32x32, 62 at 64x64)
-    std::vector<int> by_len(runs.size()), stream_of(runs.size());
-    std::vector<long> len(runs.size()), load(n_streams, 0);
-    for (size_t k = 0; k < runs.size(); k++)
+    // (the class of the smallest PUs has the longest chains: it takes the main stream and starts first)
+    int used = 0;
+    for (int cls = 0; cls < 3; cls++)
     {
-        const int f0 = runs[k].f0, pm = part_mode ? part_mode[f0] : 0;
-        int gw, gh;
-        field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
-        const int parts = field_two_rows(pm) ? 2 : 1;
-        // (the two parts of an asymmetric CU together have the CU's area: half of it each on average)
-        const double area = (double)pu_w[f0] * pu_h[f0] * (pm >= 4 ? 0.5 : 1.0);
-        len[k] = (long)(parts * (gw + 2 * (gh / parts)) * (12.0 + 0.75 * sqrt(area)));
-        by_len[k] = (int)k;
-    }
-    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return len[a] > len[b]; });
-    for (int k : by_len)
-    {
-        const int s = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        stream_of[k] = s;
-        load[s] += len[k];
-    }
-    for (int k : by_len)
-    {
-        const int f0 = runs[k].f0, nf = runs[k].f1 - f0, pm = part_mode ? part_mode[f0] : 0;
-        int gw, gh;
-        field_grid(e.width, e.height, pu_w[f0], pu_h[f0], pm, gw, gh);
-        hipStream_t st = stream_of[k] == 0 ? c->stream : c->aux[stream_of[k] - 1];
-        // (the larger part of an asymmetric CU, three quarters of it, picks the kernel)
-        const int cls = pm >= 4 ? job_class(pu_w[f0], pu_h[f0] - (pu_h[f0] >> 2)) : job_class(pu_w[f0], pu_h[f0]);
-        const int wg_rows = field_two_rows(pm) ? gh / 2 : gh;
-        x265amd_me_result *res = (x265amd_me_result*)c->field_results.p + first[f0];
-        int *mvp = (int*)c->field_mvp.p + first[f0];
-        const LookPair *pairs = (const LookPair*)c->look_pairs.p + f0;
+        if (desc[cls].empty())
+            continue;
+        hipStream_t st = used == 0 ? c->stream : c->aux[used - 1];
+        used++;
+        const FieldDesc &last = desc[cls].back();
+        const int n_wgs = last.first_wg + last.wg_rows;
+        const FieldDesc *dd = (const FieldDesc*)c->look_pairs.p + desc_at[cls];
+        x265amd_me_result *res = (x265amd_me_result*)c->field_results.p;
+        int *mvp = (int*)c->field_mvp.p;
         int *err = (int*)c->look_progress.p + ERR_WORD_FIELD;
-        const x265amd_me_result *dcol = col ? (const x265amd_me_result*)c->field_col.p + col_per * f0 : nullptr;
+        const x265amd_me_result *dcol = col ? (const x265amd_me_result*)c->field_col.p : nullptr;
         if (e.bpp == 1)
-            launch_field<uint8_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, dcol, res, mvp, err);
+            launch_field<uint8_t>(c, st, cls, n_wgs, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
         else
-            launch_field<uint16_t>(c, st, cls, nf, wg_rows, cost, pairs, pu_w[f0], pu_h[f0], gw, e.width, e.height, merange, method, subme, qp, pm, dcol, res, mvp, err);
+            launch_field<uint16_t>(c, st, cls, n_wgs, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
         HIPCHK(c, hipGetLastError());
     }
     for (int i = 0; i + 1 < n_streams; i++)

@@ -14,9 +14,9 @@
     XA_K_SEARCH(PIX, 1, 256, true, false) XA_K_SEARCH(PIX, 1, 64, true, false)
 #define XA_K_FIELD(PIX, NW, MAXG)                                                                                        \
     XA_INST __global__ void xa::k_field<xa::JobLds<PIX, NW, MAXG, false, NW == 1>>(const xa::PlaneDesc*, const uint16_t*, \
-                                                                                 const xa::LookPair*, int, int, int, int, int, int, int, \
-                                                                                 int, int, int, int, int, int, const x265amd_me_result*, x265amd_me_result*, int*, int*, \
-                                                                                 unsigned long long*);
+                                                                                 const xa::FieldDesc*, int, int, int, int, int, int, \
+                                                                                 int, int, int, const x265amd_me_result*, x265amd_me_result*, \
+                                                                                 int*, int*, unsigned long long*);
 #define XA_K_LOOK(PIX)                                                                                                   \
     XA_INST __global__ void xa::k_lookahead<xa::JobLds<PIX, 1, 64, true, true>>(const xa::PlaneDesc*, const uint16_t*,    \
                                                                               const xa::LookPair*, int, int, int, int, int, int, int, \
