@@ -1,3 +1,5 @@
+"""Developer aid: runs tests/cpp/adapter_demo on a 512x256 synthetic frame pair and prints the hit statistics of its chained-field
+walks (per shape, and the positions of the parts that missed for the 2NxN and nRx2N fields)."""
 import os, subprocess, sys
 sys.path.insert(0, os.getcwd())
 from x265_amd import synth
