@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
     int cur_top = 0;                                                     // 2NxN: MV word of the upper part of the current CU
     Wave<L> W;
     W.sliced = false;
+#ifdef XA_PROFILE
+    long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long prof_sq[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_max[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     auto clipq = [](int v, int lo, int hi) { int c = v > hi ? hi : v; return c < lo ? lo : c; };
 
     for (int gx = 0; gx < gw; gx++)
@@ -127,7 +131,9 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         }
         const bool have_l = gx > 0, have_a = gy > 0, have_ar = !lower && gy > 0 && gx + 1 < gw, have_al = gy > 0 && gx > 0;
         // (the PU is cached while the row above may still be busy)
+        W.stamp(0);
         W.bind(lds, enc, ref, px, py, px, py, bw, bh, cost, flags, true);
+        W.stamp(1);
         int w_al = 0, w_a = 0, w_ar = 0;
         if (lower)
             w_a = cur_top;                                              // (B = above exists: above-left is never asked for)
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
             w_ar = __builtin_amdgcn_readlane(v, 2);
             failed |= (w_al == LOOK_UNSET) | (w_a == LOOK_UNSET) | (w_ar == LOOK_UNSET);
         }
+        W.stamp(6);
         auto mvx = [](int word) { return XA_S16(word & 0xffff); };
         auto mvy = [](int word) { return XA_S16(word >> 16); };
         // the two AMVP candidates
@@ -227,9 +234,36 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
         if (out_mvp)
             LookLeaf::store_word(out_mvp + (size_t)gy * gw + gx, (mvpy << 16) | (mvpx & 0xffff));
         LookLeaf::publish(out + (size_t)gy * gw + gx, ox, oy, c);
+#ifdef XA_PROFILE       // developer aid: clocks per phase, summed over the PUs of every 8th row
+        W.stamp(7);
+        if ((blockIdx.x & 7) == 0)
+        {
+            const int from[8] = { 0, 1, 6, 2, 3, 4, 5, 0 }, to[8] = { 1, 6, 2, 3, 4, 5, 7, 7 };
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                // (slot 7 of the squares and maxima: the PU's own work, i.e. the loop without the wait)
+                const long long d = W.tstamp[to[k]] - W.tstamp[from[k]] - (k == 7 ? W.tstamp[6] - W.tstamp[1] : 0);
+                prof[k] += W.tstamp[to[k]] - W.tstamp[from[k]];
+                prof_sq[k] += (unsigned long long)((d >> 6) * (d >> 6));
+                prof_max[k] = (unsigned long long)d > prof_max[k] ? (unsigned long long)d : prof_max[k];
+            }
+        }
+#endif
       }
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
     LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
+#ifdef XA_PROFILE
+    if (threadIdx.x == 0 && (blockIdx.x & 7) == 0)
+        for (int k = 0; k < 8; k++)
+        {
+            atomicAdd(evals + EVAL_SLOTS * 16 + 8 + k, (unsigned long long)prof[k]);
+            atomicAdd(evals + (EVAL_SLOTS + 2) * 16 + k, prof_sq[k]);
+            atomicMax(evals + (EVAL_SLOTS + 2) * 16 + 8 + k, prof_max[k]);
+            if (k < 6)
+                atomicAdd(evals + (EVAL_SLOTS + 1) * 16 + 8 + k, (unsigned long long)W.cgen[k]);
+        }
+#endif
 }
 
 } // namespace xa

@@ -52,7 +52,7 @@ struct DevBuf
 
 } // namespace
 
-constexpr int EVAL_WORDS = (EVAL_SLOTS + 2) * 16;   // device words behind d_evals
+constexpr int EVAL_WORDS = (EVAL_SLOTS + 3) * 16;   // device words behind d_evals (the last 32 only hold profiling sums)
 
 // results to device-mapped host memory, one 64-bit word per thread
 __global__ void __launch_bounds__(256) k_copy_words(const unsigned long long *src, unsigned long long *dst, int n)
@@ -2958,6 +2958,11 @@ int x265amd_eval_count(x265amd_ctx *c, int reset, uint64_t *evals)
             fprintf(stderr, "lookahead rows (sampled), clocks: cache PU %llu  wait for the row below %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu  | whole CU loop %llu\n",
                     q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]);
         const unsigned long long *cq = &t[(size_t)(EVAL_SLOTS + 1) * 16];
+        const unsigned long long *sq = &t[(size_t)(EVAL_SLOTS + 2) * 16];
+        if (sq[7])
+            fprintf(stderr, "chained field (sampled rows): sum of (clocks / 64)^2 per phase: cache %llu  wait %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  "
+                            "publish %llu  work (loop - wait) %llu; largest per PU: cache %llu  wait %llu  mvp %llu  predictors %llu  pattern %llu  subpel %llu  publish %llu  work %llu\n",
+                    sq[0], sq[1], sq[2], sq[3], sq[4], sq[5], sq[6], sq[7], sq[8], sq[9], sq[10], sq[11], sq[12], sq[13], sq[14], sq[15]);
         if (cq[0])
             fprintf(stderr, "half-resolution sub-pel calls (sampled rows): %llu calls; clocks per call: set-up %llu  call -> entry %llu  MV costs %llu  "
                             "plane reads %llu  reduce %llu  return %llu  unpack %llu\n", cq[0], cq[1] / cq[0], cq[2] / cq[0], cq[3] / cq[0],
