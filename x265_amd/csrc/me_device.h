@@ -297,12 +297,17 @@ struct JobState
 // LR: the kernel also handles half-resolution reference sets (PlaneDesc::lr_step != 0); kernels
 // built without it are leaner and must not be given such references.
 // INL: a single-wavefront kernel that takes the evaluation code inline instead of calling it (latency-bound chains).
-template <typename PIX_, int NW_, int MAXG_, bool LR_ = false, bool INL_ = false>
+// CP: a single-wavefront class (NW = 1: the search and every evaluation run on the job's first wavefront, inline) whose workgroup
+// holds CP_WAVES - 1 further wavefronts parked at a barrier; a sub-pel round's candidates are dealt to all of them, each wavefront
+// pricing its candidates over the whole PU (Dev::cp_round).  For chains of dependent searches of ONE PU at a time (me_field.h).
+template <typename PIX_, int NW_, int MAXG_, bool LR_ = false, bool INL_ = false, bool CP_ = false>
 struct JobLds
 {
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
-    static constexpr bool LR = LR_, INL = INL_;
+    static constexpr bool LR = LR_, INL = INL_, CP = CP_;
+    static constexpr int CP_WAVES = CP_ ? 4 : 1;
+    static_assert(!CP_ || NW_ == 1, "candidate-parallel rounds are a feature of the single-wavefront classes");
     // A window of the reference plane around the search centre is kept in LDS only by the class of the largest PUs:
     // measured on MI355X, staging it costs the smaller classes more instructions than reading candidates from the
     // plane (L2) does (8x8 .. 32x32 PUs: 3 - 14 % faster without, 64x64: 6 - 16 % slower without).
@@ -318,6 +323,11 @@ struct JobLds
     uint32_t win[WIN_BYTES / 4 + 4];            // reference window
     JobState st;
     int      cmd[8];                            // command posted by the leader wave: op, arguments (NW > 1)
+    // candidate-parallel rounds: the horizontal intermediates of wavefronts 1 .. CP_WAVES - 1, the command {go, n, flags, kind}
+    // and the candidates' costs
+    int16_t  cp_imm[CP_ ? CP_WAVES - 1 : 1][CP_ ? MAXG * 4 + 8 * 64 : 4];
+    int      cp_cmd[4];
+    int      cp_res[8];
 };
 
 struct Res8 { int c[8]; };
@@ -357,12 +367,14 @@ struct Dev
     {
         LP  l;
         SP  s;
+        XA_LDS int16_t *imm;        // horizontal intermediate of HV candidates (a candidate-parallel worker has its own)
         int tid, lane, wv, G, T;
 
         __device__ __forceinline__ View(uint32_t base)
         {
             l = lds((uint32_t)uni((int)base));
-            tid = (int)threadIdx.x;
+            imm = l->imm;
+            tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;     // (a candidate-parallel workgroup has more threads than NT)
             lane = tid & 63;
             wv = wave_id();
             s = &l->st;
@@ -971,7 +983,7 @@ struct Dev
         // PRED_HV, second half: filterVertical_s_p (ipfilter.cpp:38-89) over the LDS intermediate,
         // whose row k holds picture row (k - 3) of the candidate block
         {
-            const XA_LDS int16_t *m = v.l->imm + ioff;
+            const XA_LDS int16_t *m = v.imm + ioff;
             uint32_t rw[8][2];
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -1005,7 +1017,7 @@ struct Dev
             int sm[4];
             h_ps(px, xf, depth, sm);
             const uint32_t lo = __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100), hi = __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100);
-            *(XA_LDS uint64_t*)(v.l->imm + row * w + col) = (uint64_t)lo | ((uint64_t)hi << 32);
+            *(XA_LDS uint64_t*)(v.imm + row * w + col) = (uint64_t)lo | ((uint64_t)hi << 32);
         }
         bsync();
     }
@@ -1494,6 +1506,69 @@ struct Dev
         return r;
     }
 
+    // ---------------------------------------------------------------- candidate-parallel rounds (L::CP)
+    // The n <= 8 candidates of JobState::pts / frc / lbl, read from the plane, two per wavefront: wavefront i prices candidates
+    // 2 i and 2 i + 1 (in a refinement round those are the two vertical, the two horizontal and the two pairs of diagonal
+    // neighbours, and a pair of diagonals shares its horizontal intermediate) and stores cost + MV cost in cp_res.
+    static __device__ __forceinline__ void cp_part(uint32_t base, int wave)
+    {
+        View v(base);
+        if (wave > 0)
+            v.imm = v.l->cp_imm[wave - 1];
+        const int n = uni(v.l->cp_cmd[1]), cflags = uni(v.l->cp_cmd[2]), kind = uni(v.l->cp_cmd[3]);
+        const int pitch = uni(v.s->stride);
+        Src src(v, false);
+        const int lc = label_cost(v, n, cflags);        // lane k: MV cost of candidate k
+        HvCache hc = { 0, 0, false };
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            const int k = 2 * wave + i;
+            if (k < n)
+            {
+                const int off = v.s->pts[k], frac = uni(v.s->frc[k]);
+                const int c = cost_body(v, src, false, off, pitch, frac, kind, 0, hc) + __builtin_amdgcn_readlane(lc, k);
+                if (v.lane == 0)
+                    v.l->cp_res[k] = c;
+            }
+        }
+    }
+    // leader: run one round (the candidates are in the job state)
+    static __device__ __forceinline__ Res8 cp_round(uint32_t base, int n, int cflags, int kind)
+    {
+        LP l = lds(base);
+        l->cp_cmd[0] = 1; l->cp_cmd[1] = n; l->cp_cmd[2] = cflags; l->cp_cmd[3] = kind;
+        __syncthreads();
+        cp_part(base, 0);
+        __syncthreads();
+        Res8 r;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            r.c[k] = l->cp_res[k];
+        return r;
+    }
+    static __device__ __forceinline__ void cp_exit(uint32_t base)
+    {
+        if (L::CP)
+        {
+            lds(base)->cp_cmd[0] = 0;
+            __syncthreads();
+        }
+    }
+    // wavefronts 1 .. CP_WAVES - 1: parked at the barrier between rounds
+    static __device__ __forceinline__ void cp_worker(uint32_t base, int wave)
+    {
+        LP l = lds(base);
+        for (;;)
+        {
+            __syncthreads();
+            if (uni(l->cp_cmd[0]) == 0)
+                break;
+            cp_part(base, wave);
+            __syncthreads();
+        }
+    }
+
     // ---------------------------------------------------------------- leader / worker protocol (NW > 1)
     // The search logic runs on the job's first wave only.  The other waves wait at a barrier for
     // a command {op, arguments} in JobLds::cmd, run the same cooperative function as the leader
@@ -1891,6 +1966,18 @@ struct Wave
         }
         evals += (unsigned)n;
         const int cf = where | take_par(lowres ? 1 : n);
+        if constexpr (L::CP)
+        {
+            // (PUs of at most 64 pixels price a round's candidates side by side on one wavefront already: subpel_rows)
+            if (!where && !lowres && n >= 4 && ((w * h) >> 2) > 16)
+            {
+                const Res8 r = D::cp_round(base, n, cf, kind);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    c[k] = uni(r.c[k]);
+                return;
+            }
+        }
         D::post(base, D::OP_ANY, n, cf, kind);
         const Res8 r = D::call_any(base, n, cf, kind);
 #pragma unroll

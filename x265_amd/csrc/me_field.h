@@ -65,7 +65,7 @@ struct FieldDesc
 };
 
 template <class L>
-__global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const uint16_t *cost, const FieldDesc *fields, int n_fields,
+__global__ void __launch_bounds__(L::NT * L::CP_WAVES) k_field(const PlaneDesc *planes, const uint16_t *cost, const FieldDesc *fields, int n_fields,
                                                  int pic_w, int pic_h, int max_cu, int merange, int method, int subme, int qp, int flags,
                                                  const x265amd_me_result *col, x265amd_me_result *out, int *out_mvp, int *error,
                                                  unsigned long long *evals)
@@ -93,6 +93,12 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
     if (L::NW > 1 && Dev<L>::wave_id() != 0)
     {
         Dev<L>::worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds);
+        return;
+    }
+    if (L::CP && threadIdx.x >= 64)
+    {
+        // (the candidate-parallel workers wait for the leader's first command: everything they read is written before it)
+        Dev<L>::cp_worker((uint32_t)(uintptr_t)(XA_LDS L*)&lds, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
         return;
     }
     const PlaneDesc &enc = planes[F.enc_plane];
@@ -252,6 +258,7 @@ __global__ void __launch_bounds__(L::NT) k_field(const PlaneDesc *planes, const 
 #endif
       }
     Dev<L>::post(W.base, Dev<L>::OP_EXIT);
+    Dev<L>::cp_exit(W.base);
     LookLeaf::finish(evals + (blockIdx.x % EVAL_SLOTS) * 16, n_evals, error, failed);
 #ifdef XA_PROFILE
     if (threadIdx.x == 0 && (blockIdx.x & 7) == 0)

@@ -2130,7 +2130,7 @@ void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_wgs, const uint
                   int pic_w, int pic_h, int merange, int method, int subme, int qp, const x265amd_me_result *col,
                   x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1>>), dim3(n_wgs), dim3(NW * 64), 0, st, c->d_planes, cost, \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1, NW == 1>>), dim3(n_wgs), dim3(NW == 1 ? 256 : NW * 64), 0, st, c->d_planes, cost, \
                                               fields, n_fields, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               col, res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);

@@ -13,7 +13,7 @@
     XA_K_SEARCH(PIX, 1, 256, false, true) XA_K_SEARCH(PIX, 1, 64, false, true)                                           \
     XA_K_SEARCH(PIX, 1, 256, true, false) XA_K_SEARCH(PIX, 1, 64, true, false)
 #define XA_K_FIELD(PIX, NW, MAXG)                                                                                        \
-    XA_INST __global__ void xa::k_field<xa::JobLds<PIX, NW, MAXG, false, NW == 1>>(const xa::PlaneDesc*, const uint16_t*, \
+    XA_INST __global__ void xa::k_field<xa::JobLds<PIX, NW, MAXG, false, NW == 1, NW == 1>>(const xa::PlaneDesc*, const uint16_t*, \
                                                                                  const xa::FieldDesc*, int, int, int, int, int, int, \
                                                                                  int, int, int, const x265amd_me_result*, x265amd_me_result*, \
                                                                                  int*, int*, unsigned long long*);
