@@ -1349,8 +1349,9 @@ struct Dev
     {
         return f == 0 ? a : f == 1 ? b : f == 2 ? c : d;
     }
+    // (candidates [k_lo, n): a candidate-parallel wavefront prices its share only)
     template <bool LW>
-    static __device__ __forceinline__ void subpel_rows(View &v, const Src &src, int pitch, int kind, int n, int &res)
+    static __device__ __forceinline__ void subpel_rows(View &v, const Src &src, int pitch, int kind, int n, int &res, int k_lo = 0)
     {
         static_assert(DW == 1, "8-bit pixels only");
         constexpr int step = LW ? PB : 1;
@@ -1363,15 +1364,16 @@ struct Dev
         const int gv = v.l->gxy[in_pu ? gl : 0], gx = gv & 0xff, gy = gv >> 8;
         uint32_t fd[2] = { v.l->fenc[in_pu ? gl : 0], 0 };
         const P4 f = unpack4(fd);
-        for (int c0 = 0; c0 < n; c0 += 4)
+        for (int c0 = k_lo; c0 < n; c0 += 4)
         {
             // horizontal pass, one candidate after the other: rows -3 .. h+3, one 4-value group per lane
             // ((h + 7) * w / 4 <= 44 groups for every PU of at most 16 groups)
             const int lr = v.lane >> lg, col = (v.lane & (ngx - 1)) * 4;
+            const int nq = n - c0 < 4 ? n - c0 : 4;
 #pragma nounroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < nq; q++)
             {
-                const int kk = c0 + q < n ? c0 + q : 0;
+                const int kk = c0 + q;
                 const int off = v.s->pts[kk], xf = v.s->frc[kk] & 3;
                 if (v.lane < per)
                 {
@@ -1390,7 +1392,7 @@ struct Dev
                         sm[i] = __builtin_amdgcn_sdot4((int)b, hi, __builtin_amdgcn_sdot4((int)a, lo, 0, false), false);
                     }
                     const uint32_t p01 = __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100), p23 = __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100);
-                    *(XA_LDS uint64_t*)(v.l->imm + (q * per + v.lane) * 4) = (uint64_t)p01 | ((uint64_t)p23 << 32);
+                    *(XA_LDS uint64_t*)(v.imm + (q * per + v.lane) * 4) = (uint64_t)p01 | ((uint64_t)p23 << 32);
                 }
             }
             bsync();
@@ -1401,7 +1403,7 @@ struct Dev
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 tp[i] = sel4(yf, c_luma_h2[0][i], c_luma_h2[1][i], c_luma_h2[2][i], c_luma_h2[3][i]);
-            const XA_LDS int16_t *m = v.l->imm + (row * per + gy * ngx) * 4 + gx;
+            const XA_LDS int16_t *m = v.imm + (row * per + gy * ngx) * 4 + gx;
             int sum[4] = { 2048 + 524288, 2048 + 524288, 2048 + 524288, 2048 + 524288 };
 #pragma unroll
             for (int t = 0; t < 8; t += 2)
@@ -1507,30 +1509,43 @@ struct Dev
     }
 
     // ---------------------------------------------------------------- candidate-parallel rounds (L::CP)
-    // The n <= 8 candidates of JobState::pts / frc / lbl, read from the plane, two per wavefront: wavefront i prices candidates
-    // 2 i and 2 i + 1 (in a refinement round those are the two vertical, the two horizontal and the two pairs of diagonal
-    // neighbours, and a pair of diagonals shares its horizontal intermediate) and stores cost + MV cost in cp_res.
+    // The n <= 8 candidates of JobState::pts / frc / lbl, read from the plane, dealt to the wavefronts in runs of ceil(n / 4):
+    // of a refinement round's eight, wavefront i prices candidates 2 i and 2 i + 1 - the two vertical, the two horizontal and the
+    // two pairs of diagonal neighbours, and a pair of diagonals shares its horizontal intermediate.  Cost + MV cost go to cp_res.
     static __device__ __forceinline__ void cp_part(uint32_t base, int wave)
     {
         View v(base);
         if (wave > 0)
             v.imm = v.l->cp_imm[wave - 1];
         const int n = uni(v.l->cp_cmd[1]), cflags = uni(v.l->cp_cmd[2]), kind = uni(v.l->cp_cmd[3]);
+        const int per = (n + L::CP_WAVES - 1) / L::CP_WAVES;
+        const int k_lo = wave * per, k_hi = k_lo + per < n ? k_lo + per : n;
+        if (k_lo >= k_hi)
+            return;
         const int pitch = uni(v.s->stride);
         Src src(v, false);
-        const int lc = label_cost(v, n, cflags);        // lane k: MV cost of candidate k
-        HvCache hc = { 0, 0, false };
-#pragma unroll
-        for (int i = 0; i < 2; i++)
+        int res = label_cost(v, n, cflags);             // lane k: MV cost of candidate k
+        const int pw = uni(v.s->w);
+        if (DW == 1 && v.G <= 16 && (pw & (pw - 1)) == 0)
         {
-            const int k = 2 * wave + i;
-            if (k < n)
+            if constexpr (DW == 1)
+                subpel_rows<false>(v, src, pitch, kind, k_hi, res, k_lo);
+        }
+        else
+        {
+            HvCache hc = { 0, 0, false };
+            for (int k = k_lo; k < k_hi; k++)
             {
                 const int off = v.s->pts[k], frac = uni(v.s->frc[k]);
-                const int c = cost_body(v, src, false, off, pitch, frac, kind, 0, hc) + __builtin_amdgcn_readlane(lc, k);
-                if (v.lane == 0)
-                    v.l->cp_res[k] = c;
+                const int c = cost_body(v, src, false, off, pitch, frac, kind, 0, hc);
+                res += (v.lane == k) ? c : 0;
             }
+        }
+        for (int k = k_lo; k < k_hi; k++)
+        {
+            const int c = __builtin_amdgcn_readlane(res, k);
+            if (v.lane == 0)
+                v.l->cp_res[k] = c;
         }
     }
     // leader: run one round (the candidates are in the job state)
@@ -1858,7 +1873,17 @@ struct Wave
 #ifdef XA_PROFILE
             const long long t_b = (long long)__builtin_readcyclecounter();
 #endif
-            r = D::call_any(base, n, cf, kind);
+            bool dealt = false;
+            if constexpr (L::CP && N > 1)
+            {
+                if (n >= 2 && !where && !lowres)        // several candidates from the plane: side by side on the workgroup's wavefronts
+                {
+                    r = D::cp_round(base, n, cf, kind);
+                    dealt = true;
+                }
+            }
+            if (!dealt)
+                r = D::call_any(base, n, cf, kind);
 #ifdef XA_PROFILE
             {
                 const long long t_c = (long long)__builtin_readcyclecounter() + (uni(r.c[0]) & 0);
@@ -1928,6 +1953,31 @@ struct Wave
         eval_n<1>(1, &cx, &cy, &qx, &qy, kind, &fr, with_mv ? 0 : CF_NOMV, &c);
         return c;
     }
+    // two positions without their MV costs (the template costs of two predictor candidates): side by side on two wavefronts of a
+    // candidate-parallel workgroup, else one after the other
+    __device__ __forceinline__ void subpel_cost2(const int *qx, const int *qy, int kind, int *out)
+    {
+        if constexpr (L::CP)
+        {
+            if (!lowres)
+            {
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                {
+                    s->pts[k] = block_off(0, qx[k] >> 2, qy[k] >> 2);
+                    s->lbl[k] = (qy[k] << 16) | (qx[k] & 0xffff);
+                    s->frc[k] = phase(qx[k], qy[k]);
+                }
+                evals += 2;
+                const Res8 r = D::cp_round(base, 2, CF_NOMV, kind);
+                out[0] = uni(r.c[0]);
+                out[1] = uni(r.c[1]);
+                return;
+            }
+        }
+        out[0] = subpel_cost(qx[0], qy[0], kind, false);
+        out[1] = subpel_cost(qx[1], qy[1], kind, false);
+    }
     // the same for the first n of 8 q-pel positions at once, each plus its MV cost: one refinement
     // round (motion.cpp:801-845) in a single call
     __device__ __forceinline__ void subpel_cost8(int n, const int *qx, const int *qy, int kind, int *out, int cflags = 0)
@@ -1968,8 +2018,7 @@ struct Wave
         const int cf = where | take_par(lowres ? 1 : n);
         if constexpr (L::CP)
         {
-            // (PUs of at most 64 pixels price a round's candidates side by side on one wavefront already: subpel_rows)
-            if (!where && !lowres && n >= 4 && ((w * h) >> 2) > 16)
+            if (!where && !lowres && n >= 4)
             {
                 const Res8 r = D::cp_round(base, n, cf, kind);
 #pragma unroll

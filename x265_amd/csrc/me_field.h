@@ -206,8 +206,10 @@ __global__ void __launch_bounds__(L::NT * L::CP_WAVES) k_field(const PlaneDesc *
         if (c1x != c0x || c1y != c0y)
         {
             // xGetTemplateCost of both candidates (equal candidates cost the same and the first one stays)
-            const int t0 = W.subpel_cost(clipq(c0x, xmin, xmax), clipq(c0y, ymin, ymax), X265AMD_SAD, false);
-            const int t1 = W.subpel_cost(clipq(c1x, xmin, xmax), clipq(c1y, ymin, ymax), X265AMD_SAD, false);
+            const int tqx[2] = { clipq(c0x, xmin, xmax), clipq(c1x, xmin, xmax) }, tqy[2] = { clipq(c0y, ymin, ymax), clipq(c1y, ymin, ymax) };
+            int t[2];
+            W.subpel_cost2(tqx, tqy, X265AMD_SAD, t);
+            const int t0 = t[0], t1 = t[1];
             if (t1 < t0)
             {
                 mvpx = c1x; mvpy = c1y;

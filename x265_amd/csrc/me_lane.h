@@ -33,7 +33,7 @@
 
 namespace xa {
 
-struct LaneCfg { static constexpr bool LR = false; };
+struct LaneCfg { static constexpr bool LR = false, CP = false; };
 
 // The search's small tables as 4-bit immediates: column c of a table of up to 16 rows in one 64-bit constant, entries
 // biased by +4 (all lie in [-4, 8]); a lookup is a shift and a mask instead of a per-lane memory read.

@@ -555,7 +555,7 @@ struct Search
         int pmx = clipq(j.qmvp_x, qminx, qmaxx), pmy = clipq(j.qmvp_y, qminy, qmaxy);
         int bprex = pmx, bprey = pmy;
         int bprecost;
-        if (L::LR)
+        if (L::LR || L::CP)        // (one call for all predictor candidates: side by side in a half-resolution or candidate-parallel kernel)
             bprecost = predictors_batched(pmx, pmy, bprex, bprey, qminx, qminy, qmaxx, qmaxy);
         else
         {
