@@ -388,7 +388,7 @@ int x265amd_field_me_batch(x265amd_ctx *ctx, int n_fields, const int *enc_planes
  * All fields of a call are in flight side by side - fields whose PUs fall into one kernel class (at most 256 / 1024 / 4096 pixels)
  * share a launch whatever their size and mode, and the up to three launches run on different streams - so the call takes about as
  * long as its longest chain (MI355X, 1080p: the twenty fields of the four square sizes, the 2NxN / Nx2N parts of 16 and 32 and all
- * asymmetric parts of 16, 32 and 64 in one call 11.2 ms; the slowest of them alone, 16x8 parts, 10.7 ms).
+ * asymmetric parts of 16, 32 and 64 in one call 8.8 ms; the slowest of them alone, 16x8 parts, 8.1 ms).
  *   part_mode[f] (NULL: all 0) = 0: 2Nx2N - every PU is its own CU;
  *                                1: 2NxN - CUs of pu_w x 2 pu_h, PU rows 2r / 2r + 1 are their upper / lower parts;
  *                                2: Nx2N - CUs of 2 pu_w x pu_h, PU columns 2c / 2c + 1 their left / right parts;

@@ -9,7 +9,7 @@ W, H = 1920, 1080
 eng = Engine(0)
 fr = synth.make_sequence(W, H, 2, seed=91)
 ids = [eng.upload_plane(f) for f in fr]
-for pu, method, subme in ((16, J.HEX, 5),):
+for pu, method, subme in ((8, J.HEX, 3), (16, J.HEX, 3), (32, J.HEX, 3)):
     eng.field_me(ids[1], ids[0], pu, pu, 64, method, subme, 32, fetch=False)
     eng.sync()
     eng.eval_count(reset=True)

@@ -2134,7 +2134,7 @@ void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_wgs, const uint
                                               fields, n_fields, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               col, res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
-    else if (cls == 1) XA_FIELD(4, 256);
+    else if (cls == 1) XA_FIELD(1, 256);
     else               XA_FIELD(8, 1024);
 #undef XA_FIELD
 }

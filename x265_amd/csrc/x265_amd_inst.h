@@ -43,8 +43,8 @@ XA_K_SEARCH_BIG(uint16_t)
 XA_K_SEARCH_SMALL(uint16_t)
 #endif
 #if !defined(XA_PART) || XA_PART == 5
-XA_K_FIELD(uint8_t, 1, 64) XA_K_FIELD(uint8_t, 4, 256) XA_K_FIELD(uint8_t, 8, 1024)
-XA_K_FIELD(uint16_t, 1, 64) XA_K_FIELD(uint16_t, 4, 256) XA_K_FIELD(uint16_t, 8, 1024)
+XA_K_FIELD(uint8_t, 1, 64) XA_K_FIELD(uint8_t, 1, 256) XA_K_FIELD(uint8_t, 8, 1024)
+XA_K_FIELD(uint16_t, 1, 64) XA_K_FIELD(uint16_t, 1, 256) XA_K_FIELD(uint16_t, 8, 1024)
 XA_K_LOOK(uint8_t) XA_K_LOOK(uint16_t)
 #endif
 #undef XA_K_SEARCH
