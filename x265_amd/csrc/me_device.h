@@ -298,15 +298,16 @@ struct JobState
 // built without it are leaner and must not be given such references.
 // INL: a single-wavefront kernel that takes the evaluation code inline instead of calling it (latency-bound chains).
 // CP: a single-wavefront class (NW = 1: the search and every evaluation run on the job's first wavefront, inline) whose workgroup
-// holds CP_WAVES - 1 further wavefronts parked at a barrier; a sub-pel round's candidates are dealt to all of them, each wavefront
-// pricing its candidates over the whole PU (Dev::cp_round).  For chains of dependent searches of ONE PU at a time (me_field.h).
+// holds up to CP_WAVES - 1 further wavefronts parked at a barrier (the launch's block size decides how many); a sub-pel round's
+// candidates are dealt to all of them, each wavefront pricing its candidates over the whole PU (Dev::cp_round).  For chains of
+// dependent searches of ONE PU at a time (me_field.h).
 template <typename PIX_, int NW_, int MAXG_, bool LR_ = false, bool INL_ = false, bool CP_ = false>
 struct JobLds
 {
     typedef PIX_ PIX;
     static constexpr int NW = NW_, MAXG = MAXG_, NT = NW_ * 64, DW = PixTraits<PIX_>::DW;
     static constexpr bool LR = LR_, INL = INL_, CP = CP_;
-    static constexpr int CP_WAVES = CP_ ? 4 : 1;
+    static constexpr int CP_WAVES = CP_ ? 8 : 1;
     static_assert(!CP_ || NW_ == 1, "candidate-parallel rounds are a feature of the single-wavefront classes");
     // A window of the reference plane around the search centre is kept in LDS only by the class of the largest PUs:
     // measured on MI355X, staging it costs the smaller classes more instructions than reading candidates from the
@@ -1518,7 +1519,8 @@ struct Dev
         if (wave > 0)
             v.imm = v.l->cp_imm[wave - 1];
         const int n = uni(v.l->cp_cmd[1]), cflags = uni(v.l->cp_cmd[2]), kind = uni(v.l->cp_cmd[3]);
-        const int per = (n + L::CP_WAVES - 1) / L::CP_WAVES;
+        const int nw = (int)(blockDim.x >> 6);          // wavefronts of the workgroup (the launch's choice, at most CP_WAVES)
+        const int per = (n + nw - 1) / nw;
         const int k_lo = wave * per, k_hi = k_lo + per < n ? k_lo + per : n;
         if (k_lo >= k_hi)
             return;

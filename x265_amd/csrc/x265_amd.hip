@@ -2126,11 +2126,11 @@ const x265amd_me_result *x265amd_lookahead_results_device(const x265amd_ctx *c)
 extern "C++" {
 namespace {
 template <typename PIX>
-void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_wgs, const uint16_t *cost, const FieldDesc *fields, int n_fields,
+void launch_field(x265amd_ctx *c, hipStream_t st, int cls, int n_wgs, int cp_waves, const uint16_t *cost, const FieldDesc *fields, int n_fields,
                   int pic_w, int pic_h, int merange, int method, int subme, int qp, const x265amd_me_result *col,
                   x265amd_me_result *res, int *mvp, int *error)
 {
-#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1, NW == 1>>), dim3(n_wgs), dim3(NW == 1 ? 256 : NW * 64), 0, st, c->d_planes, cost, \
+#define XA_FIELD(NW, MAXG) hipLaunchKernelGGL((k_field<JobLds<PIX, NW, MAXG, false, NW == 1, NW == 1>>), dim3(n_wgs), dim3(NW == 1 ? 64 * cp_waves : NW * 64), 0, st, c->d_planes, cost, \
                                               fields, n_fields, pic_w, pic_h, 64, merange, method, subme, qp, c->flags,   \
                                               col, res, mvp, error, c->d_evals)
     if (cls == 0)      XA_FIELD(1, 64);
@@ -2270,6 +2270,17 @@ int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_pla
         for (int i = 0; i + 1 < n_streams; i++)
             HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
     }
+    // Wavefronts per workgroup of the two candidate-parallel classes: eight price a round of eight candidates in the time of one,
+    // but a call with many PU rows would no longer fit the GPU at once (rows dispatched late start their chains late): four then
+    // (MI355X, 1080p, one session: one 16x16 field 4.36 ms with eight against 4.80 with four, one 32x32 field 3.97 against 4.56; eight
+    // 16x16 fields in one call, 536 workgroups, 5.27 either way; sixteen, 1072 workgroups, 9.7 against 5.8).
+    int wgs_total = 0;
+    for (int cls = 0; cls < 3; cls++)
+        for (const FieldDesc &d : desc[cls])
+            wgs_total += d.wg_rows;
+    int cp_waves = wgs_total <= 600 ? 8 : 4;
+    if (const char *ev = getenv("X265AMD_CP_WAVES"))      // (tuning aid: 1 .. 8)
+        cp_waves = std::min(8, std::max(1, atoi(ev)));
     // (the class of the smallest PUs has the longest chains: it takes the main stream and starts first)
     int used = 0;
     for (int cls = 0; cls < 3; cls++)
@@ -2286,9 +2297,9 @@ int x265amd_field_me_multi_tmvp(x265amd_ctx *c, int n_fields, const int *enc_pla
         int *err = (int*)c->look_progress.p + ERR_WORD_FIELD;
         const x265amd_me_result *dcol = col ? (const x265amd_me_result*)c->field_col.p : nullptr;
         if (e.bpp == 1)
-            launch_field<uint8_t>(c, st, cls, n_wgs, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
+            launch_field<uint8_t>(c, st, cls, n_wgs, cp_waves, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
         else
-            launch_field<uint16_t>(c, st, cls, n_wgs, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
+            launch_field<uint16_t>(c, st, cls, n_wgs, cp_waves, cost, dd, (int)desc[cls].size(), e.width, e.height, merange, method, subme, qp, dcol, res, mvp, err);
         HIPCHK(c, hipGetLastError());
     }
     for (int i = 0; i + 1 < n_streams; i++)
