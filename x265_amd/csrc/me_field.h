@@ -30,6 +30,13 @@
 // is the one of the lookahead kernel (me_lowres.h): one 64-bit device-scope store per result into an array
 // pre-filled with an impossible MV, polled by the row below with device-scope loads; a row waits only on
 // the row dispatched just before it, and a time limit turns a lost predecessor into an error code.
+//
+// A field's time is its chain of dependent PUs (PUs per row + twice the rows), each PU a chain of dependent evaluation calls, so what
+// counts is the latency of one PU's search.  The classes of PUs of at most 256 and at most 1024 pixels therefore run the search and
+// every single evaluation inline on the row's first wavefront and keep three or seven more wavefronts parked at a barrier
+// (JobLds::CP, me_device.h): a call that prices several candidates read from the plane - the 4 or 8 neighbours of a sub-pel round,
+// the two template costs, the predictor candidates - is dealt to all of them, each wavefront pricing its candidates over the whole
+// PU, and the costs come back through LDS.  The class of the largest PUs splits the PU's pixels over eight wavefronts instead.
 #pragma once
 
 #include "me_lowres.h"
