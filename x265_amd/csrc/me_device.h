@@ -1352,7 +1352,10 @@ struct Dev
     }
     // (candidates [k_lo, n): a candidate-parallel wavefront prices its share only)
     template <bool LW>
-    static __device__ __forceinline__ void subpel_rows(View &v, const Src &src, int pitch, int kind, int n, int &res, int k_lo = 0)
+    // lbl_n > 0: also add the MV costs of the lbl_n labels to `res` (lane k: candidate k) - looked up while the first pixel reads
+    // are in flight.
+    static __device__ __forceinline__ void subpel_rows(View &v, const Src &src, int pitch, int kind, int n, int &res, int k_lo = 0,
+                                                       int lbl_n = 0, int lbl_flags = 0)
     {
         static_assert(DW == 1, "8-bit pixels only");
         constexpr int step = LW ? PB : 1;
@@ -1380,6 +1383,8 @@ struct Dev
                 {
                     uint32_t px[6];
                     src.template rd12_packed<LW>(off + (lr - 3) * pitch + (col - 3) * step, px);
+                    if (lbl_n > 0 && c0 == k_lo && q == 0)
+                        res += label_cost(v, lbl_n, lbl_flags);
                     const int lo = sel4(xf, c_luma_b4[0][0], c_luma_b4[1][0], c_luma_b4[2][0], c_luma_b4[3][0]);
                     const int hi = sel4(xf, c_luma_b4[0][1], c_luma_b4[1][1], c_luma_b4[2][1], c_luma_b4[3][1]);
                     const uint32_t b0 = px[0] ^ 0x80808080u, b1 = px[1] ^ 0x80808080u, b2 = px[2] ^ 0x80808080u;
@@ -1526,15 +1531,16 @@ struct Dev
             return;
         const int pitch = uni(v.s->stride);
         Src src(v, false);
-        int res = label_cost(v, n, cflags);             // lane k: MV cost of candidate k
+        int res = 0;                                    // lane k: cost + MV cost of candidate k
         const int pw = uni(v.s->w);
         if (DW == 1 && v.G <= 16 && (pw & (pw - 1)) == 0)
         {
             if constexpr (DW == 1)
-                subpel_rows<false>(v, src, pitch, kind, k_hi, res, k_lo);
+                subpel_rows<false>(v, src, pitch, kind, k_hi, res, k_lo, n, cflags);
         }
         else
         {
+            res = label_cost(v, n, cflags);
             HvCache hc = { 0, 0, false };
             for (int k = k_lo; k < k_hi; k++)
             {
