@@ -123,6 +123,31 @@ def test_1080p_fields_with_a_co_located_field_each_in_one_call(eng, oracle):
         eng.release_plane(i)
 
 
+@pytest.mark.parametrize("waves", [1, 3, 4, 8])
+def test_fields_with_every_number_of_wavefronts_per_row(eng, oracle, waves, monkeypatch):
+    """the candidate-parallel classes (PUs of at most 1024 pixels) deal a call's candidates to the wavefronts of the row's workgroup;
+    the library picks eight or four by the size of the call - here every count is forced (X265AMD_CP_WAVES, read per call): six
+    fields of both classes and all kinds of parts with sub-pel rounds of eight candidates, each equal to the oracle's"""
+    monkeypatch.setenv("X265AMD_CP_WAVES", str(waves))
+    W, H = 416, 240
+    fr = synth.make_sequence(W, H, 2, seed=95)
+    ids = [eng.upload_plane(f) for f in fr]
+    shapes = [(8, 8, 0), (16, 16, 0), (32, 32, 0), (16, 8, 1), (32, 32, 6), (64, 64, 4)]
+    n = len(shapes)
+    eng.eval_count(reset=True)
+    got = eng.field_me_multi([ids[1]] * n, [ids[0]] * n, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes],
+                             24, J.UMH, 6, 29)
+    total = 0
+    for (pw, ph, pm), (res, mvp) in zip(shapes, got):
+        exp, exp_mvp, evals = oracle.field_me(fr[1], fr[0], pw, ph, 24, J.UMH, 6, 29, part_mode=pm)
+        assert np.array_equal(res, exp), ((pw, ph, pm), np.argwhere(res != exp)[:5])
+        assert np.array_equal(mvp, exp_mvp), (pw, ph, pm)
+        total += evals
+    assert eng.eval_count() == total
+    for i in ids:
+        eng.release_plane(i)
+
+
 def test_1080p_asymmetric_fields_beside_the_square_ones_in_one_call(eng, oracle):
     """one call, one 1080p frame: the four asymmetric fields of the 32x32 CUs, two of the 16x16 and two of the 64x64 CUs beside
     the 2Nx2N field of 32x32; every field and the evaluation total equal the oracle's"""
