@@ -632,7 +632,7 @@ def main():
     line["pcie_inclusive"] = {"workload": "enc and ref planes copied host->device and the MV/cost field device->host every frame, "
                                           "frames not overlapped", **pcie}
 
-    # The same with the frames pipelined (SURVEY 8(d)'s wall-clock including H2D and D2H): two sets of planes; the planes of frame
+    # The same with the frames pipelined (the wall-clock figure that includes the host-to-device and device-to-host copies): two sets of planes; the planes of frame
     # k + 1 are refilled through the library (x265amd_plane_refill_async: behind the searches queued so far, beside the search of
     # frame k) and the field of frame k comes down behind its search (x265amd_joblist_results_async into page-locked memory);
     # the host waits once at the end
